@@ -1,0 +1,208 @@
+/*
+ * siftgpu.h -- C ABI of libsiftgpu, the MI355X (gfx950) SIFT extraction path.
+ *
+ * The library replaces the CPU pipeline behind the free functions of the reference's
+ * sift/sift.h (Jia-Baos/SIFT).  Each entry point below names the reference interface it
+ * stands in for (file:line into the reference tree).  Plain pointers and sizes only; no C++
+ * or framework types cross this boundary.  A host-side C++ mirror of sift/sift.h that calls
+ * these functions lives in sift_amd/host/.
+ *
+ * Conventions
+ *   - every function returns SG_OK (0) or a negative sg_status; nothing throws, nothing prints
+ *     unless sg_params.verbose is set;
+ *   - outputs are caller-allocated with an explicit capacity; if a result does not fit the call
+ *     returns SG_E_CAPACITY and stores the required count where a count is returned;
+ *   - images are row-major; "stride" is in bytes for 8-bit input and in elements for double planes;
+ *   - a context belongs to one HIP device and one stream; a context is not thread-safe, distinct
+ *     contexts are independent;
+ *   - there is no CPU fallback: without a usable HIP device sg_create fails with SG_E_HIP.
+ */
+#ifndef SIFTGPU_H
+#define SIFTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sg_status {
+    SG_OK = 0,
+    SG_E_INVALID = -1,     /* bad argument */
+    SG_E_HIP = -2,         /* HIP runtime error (see sg_last_error) */
+    SG_E_CAPACITY = -3,    /* output or internal buffer too small */
+    SG_E_UNSUPPORTED = -4, /* parameter combination the path does not implement */
+    SG_E_NOMEM = -5
+} sg_status;
+
+typedef enum sg_precision {
+    SG_F64 = 0, /* pyramid stored and filtered in double, like the reference's pixel_t (sift.h:16) */
+    SG_F32 = 1  /* pyramid stored in float; keypoint arithmetic stays in double */
+} sg_precision;
+
+/* Same layout as the reference's struct Keypoint (sift/sift.h:75-102): 1120 bytes. */
+typedef struct sg_keypoint {
+    int octave;
+    int interval;
+    double offset_interval;
+    int x;
+    int y;
+    double scale;
+    double dx;
+    double dy;
+    double offset_x;
+    double offset_y;
+    double octave_scale;
+    double ori;
+    int descr_length;
+    double descriptor[128];
+    double val;
+} sg_keypoint;
+
+/* Compact feature for throughput mode: position/scale/orientation in the input image's frame
+ * (Keypoint.dx, .dy, .scale, .ori) and the 128 integer-valued descriptor bins. 144 bytes. */
+typedef struct sg_packed_feature {
+    float x, y, scale, ori;
+    uint8_t desc[128];
+} sg_packed_feature;
+
+/* The five counters DetectionLocalExtrema prints (sift/sift.cpp:984-986). */
+typedef struct sg_counters {
+    unsigned long long cc00, cc0, cc1, cc2, cc3;
+} sg_counters;
+
+/* Defaults are the macros of sift/sift.h:19-70. */
+typedef struct sg_params {
+    double sigma;      /* SIGMA 1.6 */
+    int intervals;     /* INTERVALS 3; only 3 is supported (the reference hard-wires the macro at
+                          sift.cpp:870,886,1325,1613, so other values are inconsistent there) */
+    int precision;     /* sg_precision */
+    int nointerval;    /* 0: 3x3x3 extremum test (Sift); 1: in-layer 3x3 test (Sift_nointerval) */
+    int max_width;     /* largest input image the context is sized for */
+    int max_height;
+    int max_batch;     /* images processed per sg_extract_batch* call */
+    int max_features;  /* per-image feature capacity; 0 = derived from the image size */
+    int device;        /* HIP device ordinal */
+    int verbose;
+    int keep_prequant; /* also keep the float descriptor before quantisation (debug/parity) */
+} sg_params;
+
+typedef struct sg_ctx sg_ctx;
+
+void sg_default_params(sg_params *p);
+const char *sg_strerror(int status);
+const char *sg_last_error(const sg_ctx *ctx);
+int sg_device_count(void);
+
+int sg_create(const sg_params *p, sg_ctx **out);
+int sg_destroy(sg_ctx *ctx);
+int sg_sync(sg_ctx *ctx);
+
+/* ---- whole path ---------------------------------------------------------------------------- */
+
+/* Sift(src, features, sigma, intervals) / Sift_nointerval (sift/sift.h:139,141; sift.cpp:1646-1770).
+ * Host 8-bit image in (>=3 interleaved channels, b,g,r first), reference-layout records out, ordered
+ * by ascending scale, exact ties in emission order (octave, interval, y, x, orientation bin). */
+int sg_extract(sg_ctx *ctx, const uint8_t *px, int width, int height, int channels, size_t stride,
+               sg_keypoint *out, size_t cap, size_t *n);
+
+/* Throughput form of the same path: n_img device-resident images of one size (image i starts at
+ * d_imgs + i*img_stride), packed features written to d_out + i*cap_per_image, counts to d_counts[i].
+ * Asynchronous on the context's stream; sg_sync() waits and reports capacity overflow. */
+int sg_extract_batch_device(sg_ctx *ctx, const uint8_t *d_imgs, int n_img, int width, int height,
+                            int channels, size_t stride, size_t img_stride,
+                            sg_packed_feature *d_out, size_t cap_per_image, uint32_t *d_counts);
+
+/* Host-pointer convenience form: uploads, runs sg_extract_batch_device, downloads. */
+int sg_extract_batch(sg_ctx *ctx, const uint8_t *const *imgs, int n_img, int width, int height,
+                     int channels, size_t stride, sg_packed_feature *out, size_t cap_per_image,
+                     uint32_t *counts);
+
+/* ---- stage entry points (host pointers; upload -> kernel -> download) ------------------------ */
+
+/* ConvertToGray (sift.h:115, sift.cpp:20-51) */
+int sg_convert_to_gray(sg_ctx *ctx, const uint8_t *px, int width, int height, int channels, size_t stride,
+                       double *dst);
+/* UpSample (sift.h:119, sift.cpp:111-175): dst is 2*height x 2*width */
+int sg_upsample(sg_ctx *ctx, const double *src, int width, int height, double *dst);
+/* DownSample (sift.h:117, sift.cpp:59-103): dst is (height/2) x (width/2) */
+int sg_downsample(sg_ctx *ctx, const double *src, int width, int height, double *dst);
+/* GaussianSmooth (sift.h:125, sift.cpp:323-326) = cv::GaussianBlur(src,dst,Size(0,0),sigma,sigma) */
+int sg_gaussian_smooth(sg_ctx *ctx, const double *src, double *dst, int width, int height, double sigma);
+/* CreateInitSmoothGray (sift.h:127, sift.cpp:335-346): dst is 2*height x 2*width */
+int sg_create_init_smooth_gray(sg_ctx *ctx, const uint8_t *px, int width, int height, int channels,
+                               size_t stride, double sigma, double *dst);
+/* GaussianPyramid (sift.h:129, sift.cpp:357-407): levels[o*(intervals+3)+i] receives octave o, level i */
+int sg_gaussian_pyramid(sg_ctx *ctx, const double *base, int width, int height, int octaves, int intervals,
+                        double sigma, double *const *levels);
+/* Sub (sift.h:131, sift.cpp:416-437): c = a - b */
+int sg_sub(sg_ctx *ctx, const double *a, const double *b, double *c, int width, int height);
+/* DogPyramid (sift.h:133, sift.cpp:447-461): dog[o*(intervals+2)+i-1] = gauss[o*(S+3)+i] - gauss[o*(S+3)+i-1] */
+int sg_dog_pyramid(sg_ctx *ctx, const double *const *gauss, int width, int height, int octaves, int intervals,
+                   double *const *dog);
+/* DetectionLocalExtrema / _nointerval (sift.h:135,137; sift.cpp:920-1056) on a DoG pyramid whose octave 0
+ * is height x width; records have octave, interval, x, y, offsets, dx, dy, val filled (sift.cpp:895-907,962). */
+int sg_detect_local_extrema(sg_ctx *ctx, const double *const *dog, int width, int height, int octaves,
+                            int intervals, int nointerval, sg_keypoint *out, size_t cap, size_t *n,
+                            sg_counters *counters);
+/* CalculateScale + HalfFeatures (sift.cpp:1065-1096), in place (host arithmetic on n records) */
+int sg_calculate_scale(sg_keypoint *kp, size_t n, double sigma, int intervals);
+int sg_half_features(sg_keypoint *kp, size_t n);
+/* OrientationAssignment (sift.cpp:1317-1339): one output record per orientation peak */
+int sg_orientation_assignment(sg_ctx *ctx, const sg_keypoint *extrema, size_t n_extrema,
+                              const double *const *gauss, int width, int height, int octaves,
+                              sg_keypoint *out, size_t cap, size_t *n);
+/* DescriptorRepresentation (sift.cpp:1607-1631): fills descr_length and descriptor of each record */
+int sg_descriptor_representation(sg_ctx *ctx, sg_keypoint *features, size_t n, const double *const *gauss,
+                                 int width, int height, int octaves);
+/* std::sort(features, FeatureCmp) (sift.cpp:1640-1643,1703): ascending scale, ties keep input order */
+int sg_sort_features(sg_ctx *ctx, sg_keypoint *features, size_t n);
+
+/* ---- inspection of the last sg_extract / batch call (parity tests, diagnostics) -------------- */
+
+int sg_last_octaves(const sg_ctx *ctx);
+int sg_level_dims(const sg_ctx *ctx, int octave, int *rows, int *cols);
+/* Gaussian level (octave, level 0..5) of image `image` of the last call, converted to double */
+int sg_read_level(sg_ctx *ctx, int image, int octave, int level, double *dst);
+int sg_read_counters(sg_ctx *ctx, int image, sg_counters *out);
+/* keypoints after scale assignment and halving, in the reference's emission order */
+int sg_read_keypoints(sg_ctx *ctx, int image, sg_keypoint *out, size_t cap, size_t *n);
+/* features in emission order (before the scale sort) with descriptors; prequant (n x 128, may be NULL)
+ * needs sg_params.keep_prequant */
+int sg_read_features_unsorted(sg_ctx *ctx, int image, sg_keypoint *out, size_t cap, size_t *n, double *prequant);
+
+/* ---- timing: HIP events recorded on the context's stream around each stage ------------------- */
+
+typedef enum sg_stage {
+    SG_ST_PREP = 0,   /* gray + upsample */
+    SG_ST_BLUR_ROW,   /* all row-pass launches */
+    SG_ST_BLUR_COL,   /* all column-pass launches */
+    SG_ST_DOWNSAMPLE,
+    SG_ST_DETECT,     /* fused DoG + extrema scan */
+    SG_ST_COMPACT,    /* ordered compaction launches */
+    SG_ST_REFINE,
+    SG_ST_ORIENT,
+    SG_ST_DESCR,
+    SG_ST_SORT,       /* rank + output packing */
+    SG_ST_COUNT
+} sg_stage;
+
+int sg_set_profiling(sg_ctx *ctx, int on);
+/* Accumulated milliseconds and launch counts per stage since the last reset; waits for the stream. */
+int sg_get_stage_times(sg_ctx *ctx, double *ms /* SG_ST_COUNT */, unsigned long long *launches /* SG_ST_COUNT */);
+int sg_reset_stage_times(sg_ctx *ctx);
+
+/* ---- device memory and synthetic input (so that callers need no HIP binding of their own) ---- */
+
+int sg_malloc(sg_ctx *ctx, size_t bytes, void **d_ptr);
+int sg_free(sg_ctx *ctx, void *d_ptr);
+int sg_memcpy_h2d(sg_ctx *ctx, void *d_dst, const void *src, size_t bytes);
+int sg_memcpy_d2h(sg_ctx *ctx, void *dst, const void *d_src, size_t bytes);
+/* 5-octave value-noise test image (b=g=r), generated on the device: height x width x 3 bytes */
+int sg_synth_vnoise5(sg_ctx *ctx, uint8_t *d_dst, int width, int height, uint64_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,473 @@
+// kernels_detect.hip -- fused DoG + local-extrema scan with wavefront-ballot compaction, ordered
+// compaction primitives (scan, expand), and sub-pixel refinement + contrast + edge tests.  gfx950 only.
+//
+// Ordering: the scan writes one 64-bit ballot word per (layer, row, 64-pixel segment); words are laid
+// out in the reference's raster order (octave, layer, y, x), so expanding the set bits in word order
+// reproduces the emission order of the reference's nested loops (sift/sift.cpp:925-938) without a sort.
+#include "sg_internal.h"
+
+namespace sg {
+
+// DoG level accessor: either a stored DoG pyramid or the difference of two Gaussian levels computed
+// in the pyramid's own type (exactly what a stored DoG level of that type would hold).
+template <typename T, bool FROM_DOG>
+struct DogAt {
+    __device__ static __forceinline__ T at(const OctaveTab &tab, int o, int l, size_t off)
+    {
+        if (FROM_DOG)
+            return ((const T *)tab.lv[o][l])[off];
+        return ((const T *)tab.lv[o][l + 1])[off] - ((const T *)tab.lv[o][l])[off];
+    }
+};
+
+// ---- fused DoG + extrema scan ----------------------------------------------------------------------
+// One wave owns a 64-pixel segment of RS consecutive rows and all three scanned layers.  Each lane
+// keeps, for the 5 DoG levels, a 3-row x 3-column window in registers and slides it down the rows.
+// isExtremum (reference sift/sift.cpp:473-526): val > 0 -> no neighbour (27 incl. centre) greater;
+// otherwise no neighbour smaller.  Pre-threshold |val| > thresh is strict (sift.cpp:945).
+template <typename T, bool FROM_DOG, bool NOINT, int RS>
+__global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned long long *words, size_t words_img,
+                                                unsigned int *chunk_sums, size_t chunks_img,
+                                                unsigned long long *counters, double thresh)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
+    const int b = blockIdx.z;
+    const int k = blockIdx.x;
+    const int x = kBorder + 64 * k + lane;
+    const bool x_ok = x < cols - kBorder;
+    const int xc = x_ok ? x : cols - kBorder - 1; // clamped column for loads; results masked by x_ok
+    const int y_begin = kBorder + (blockIdx.y * 4 + wave) * RS;
+    if (y_begin >= rows - kBorder)
+        return;
+    const int y_end = min(y_begin + RS, rows - kBorder);
+    const size_t img = (size_t)b * tab.img_stride[o];
+    const int nrows = tab.nrows[o], wpr = tab.wpr[o];
+    unsigned long long *wbase = words + (size_t)b * words_img + tab.wbase[o];
+    unsigned int *csum = chunk_sums + (size_t)b * chunks_img;
+
+    T d[3][kDogLevels][3]; // [row slot][dog level][column x-1..x+1]
+    auto load_row = [&](int slot, int y) {
+        size_t off = img + (size_t)y * pitch + xc;
+        if (FROM_DOG) {
+#pragma unroll
+            for (int l = 0; l < kDogLevels; l++) {
+                const T *p = (const T *)tab.lv[o][l] + off;
+                d[slot][l][0] = p[-1]; d[slot][l][1] = p[0]; d[slot][l][2] = p[1];
+            }
+        } else {
+            T g[kLevels][3];
+#pragma unroll
+            for (int l = 0; l < kLevels; l++) {
+                const T *p = (const T *)tab.lv[o][l] + off;
+                g[l][0] = p[-1]; g[l][1] = p[0]; g[l][2] = p[1];
+            }
+#pragma unroll
+            for (int l = 0; l < kDogLevels; l++) {
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    d[slot][l][c] = g[l + 1][c] - g[l][c];
+            }
+        }
+    };
+
+    unsigned int n00 = 0, n0 = 0, n1 = 0;
+    load_row(0, y_begin - 1);
+    load_row(1, y_begin);
+    for (int y = y_begin; y < y_end; y++) {
+        load_row(2, y + 1);
+        // per-level 3x3 max and min
+        T mx[kDogLevels], mn[kDogLevels];
+#pragma unroll
+        for (int l = 0; l < kDogLevels; l++) {
+            T a = d[0][l][0], i = a;
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    a = d[r][l][c] > a ? d[r][l][c] : a;
+                    i = d[r][l][c] < i ? d[r][l][c] : i;
+                }
+            }
+            mx[l] = a; mn[l] = i;
+        }
+        n00 += __popcll(__ballot(x_ok));
+#pragma unroll
+        for (int layer = 1; layer <= 3; layer++) {
+            T val = d[1][layer][1];
+            bool pre = x_ok && (fabs((double)val) > thresh);
+            T hi = mx[layer], lo = mn[layer];
+            if (!NOINT) {
+                hi = mx[layer - 1] > hi ? mx[layer - 1] : hi;
+                hi = mx[layer + 1] > hi ? mx[layer + 1] : hi;
+                lo = mn[layer - 1] < lo ? mn[layer - 1] : lo;
+                lo = mn[layer + 1] < lo ? mn[layer + 1] : lo;
+            }
+            bool ext = pre && (val > (T)0 ? !(val < hi) : !(val > lo));
+            unsigned long long mpre = __ballot(pre);
+            unsigned long long mext = __ballot(ext);
+            n0 += __popcll(mpre);
+            n1 += __popcll(mext);
+            if (lane == 0) {
+                unsigned int widx = ((unsigned int)(layer - 1) * nrows + (y - kBorder)) * wpr + k;
+                wbase[widx] = mext;
+                if (mext)
+                    atomicAdd(&csum[(tab.wbase[o] + widx) / kChunkWords], (unsigned int)__popcll(mext));
+            }
+        }
+        // slide the window down one row
+#pragma unroll
+        for (int l = 0; l < kDogLevels; l++) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                d[0][l][c] = d[1][l][c];
+                d[1][l][c] = d[2][l][c];
+            }
+        }
+    }
+    if (lane == 0) {
+        unsigned long long *ctr = counters + (size_t)b * 8;
+        atomicAdd(&ctr[0], (unsigned long long)n00 * 3ull); // one count per layer
+        atomicAdd(&ctr[1], (unsigned long long)n0);
+        atomicAdd(&ctr[2], (unsigned long long)n1);
+    }
+}
+
+void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words, size_t words_img_stride,
+                   unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
+                   double thresh, int nointerval, int prec, hipStream_t s)
+{
+    if (tab.nrows[o] <= 0 || tab.wpr[o] <= 0)
+        return;
+    constexpr int RS = 16;
+    dim3 g(tab.wpr[o], (tab.nrows[o] + 4 * RS - 1) / (4 * RS), B);
+#define SG_DET(T, FD, NI)                                                                                      \
+    detect_k<T, FD, NI, RS><<<g, 256, 0, s>>>(tab, o, words, words_img_stride, chunk_sums, chunks_img_stride, \
+                                              counters, thresh)
+    bool fd = tab.from_dog != 0, ni = nointerval != 0;
+    if (prec == SG_F64) {
+        if (fd) { if (ni) SG_DET(double, true, true); else SG_DET(double, true, false); }
+        else { if (ni) SG_DET(double, false, true); else SG_DET(double, false, false); }
+    } else {
+        if (fd) { if (ni) SG_DET(float, true, true); else SG_DET(float, true, false); }
+        else { if (ni) SG_DET(float, false, true); else SG_DET(float, false, false); }
+    }
+#undef SG_DET
+}
+
+// ---- ordered compaction: exclusive scan of per-chunk popcounts, then bit expansion ---------------------
+
+__device__ __forceinline__ unsigned int wave_incl_scan(unsigned int v, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        unsigned int t = __shfl_up(v, d);
+        if (lane >= d)
+            v += t;
+    }
+    return v;
+}
+
+// One block per image: in-place exclusive scan of n values, total to totals[b].
+__global__ __launch_bounds__(1024) void scan_k(unsigned int *sums, size_t img_stride, int n, unsigned int *totals,
+                                               unsigned int cap, unsigned int *overflow)
+{
+    __shared__ unsigned int wsum[16];
+    __shared__ unsigned int carry_s;
+    unsigned int *a = sums + (size_t)blockIdx.x * img_stride;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0)
+        carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + threadIdx.x;
+        unsigned int v = i < n ? a[i] : 0;
+        unsigned int inc = wave_incl_scan(v, lane);
+        if (lane == 63)
+            wsum[wave] = inc;
+        __syncthreads();
+        unsigned int woff = 0;
+        for (int w = 0; w < wave; w++)
+            woff += wsum[w];
+        unsigned int carry = carry_s;
+        if (i < n)
+            a[i] = carry + woff + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023)
+            carry_s = carry + woff + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        unsigned int t = carry_s;
+        totals[blockIdx.x] = t < cap ? t : cap;
+        if (t > cap)
+            atomicMax(overflow, t);
+    }
+}
+
+void launch_scan(unsigned int *chunk_sums, size_t chunks_img_stride, int n_chunks, unsigned int *totals,
+                 unsigned int cap, unsigned int *overflow, int B, hipStream_t s)
+{
+    scan_k<<<B, 1024, 0, s>>>(chunk_sums, chunks_img_stride, n_chunks, totals, cap, overflow);
+}
+
+// One block per chunk of kChunkWords words (256 threads x 4 consecutive words).
+// dyn_items (optional): per-image item count, items_per_word items to a word; words at or beyond
+// ceil(items/items_per_word) hold stale bits from earlier calls and are ignored.
+__global__ __launch_bounds__(256) void expand_k(const unsigned long long *words, size_t words_img, unsigned int n_words,
+                                                const unsigned int *dyn_items, unsigned int items_per_word,
+                                                const unsigned int *chunk_offs,
+                                                size_t chunks_img, unsigned int *out, size_t out_img, unsigned int cap)
+{
+    __shared__ unsigned int wsum[4];
+    const int b = blockIdx.y;
+    const unsigned int chunk = blockIdx.x;
+    const unsigned long long *w = words + (size_t)b * words_img;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (dyn_items) {
+        unsigned int nw = (dyn_items[b] + items_per_word - 1u) / items_per_word;
+        n_words = nw < n_words ? nw : n_words;
+    }
+    if (chunk * kChunkWords >= n_words)
+        return;
+    unsigned int w0 = chunk * kChunkWords + threadIdx.x * 4;
+    unsigned long long m[4];
+    unsigned int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        m[q] = (w0 + q < n_words) ? w[w0 + q] : 0ull;
+        cnt += __popcll(m[q]);
+    }
+    unsigned int inc = wave_incl_scan(cnt, lane);
+    if (lane == 63)
+        wsum[wave] = inc;
+    __syncthreads();
+    unsigned int pos = chunk_offs[(size_t)b * chunks_img + chunk] + inc - cnt;
+    for (int q = 0; q < wave; q++)
+        pos += wsum[q];
+    unsigned int *o = out + (size_t)b * out_img;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned long long mm = m[q];
+        while (mm) {
+            int bit = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            if (pos < cap)
+                o[pos] = (w0 + q) * 64u + (unsigned int)bit;
+            pos++;
+        }
+    }
+}
+
+void launch_expand(const unsigned long long *words, size_t words_img_stride, unsigned int n_words,
+                   const unsigned int *dyn_items, unsigned int items_per_word, const unsigned int *chunk_offs,
+                   size_t chunks_img_stride, unsigned int *out,
+                   size_t out_img_stride, unsigned int cap, int B, hipStream_t s)
+{
+    if (n_words == 0)
+        return;
+    dim3 g((n_words + kChunkWords - 1) / kChunkWords, B);
+    expand_k<<<g, 256, 0, s>>>(words, words_img_stride, n_words, dyn_items, items_per_word, chunk_offs, chunks_img_stride, out, out_img_stride, cap);
+}
+
+// ---- refinement ------------------------------------------------------------------------------------------
+// InterploationExtremum, GetOffsetX, Hessian3D, DerivativeOf3D, Inverse3D, GetFabsDx, passEdgeResponse
+// (reference sift/sift.cpp:600-910), then CalculateScale and HalfFeatures (sift.cpp:1065-1096).
+// One thread per candidate, double arithmetic in the reference's operation order.
+
+template <typename T, bool FROM_DOG>
+struct Dog3 {
+    const OctaveTab &tab;
+    int o;
+    size_t img;
+    int pitch;
+    __device__ __forceinline__ double at(int l, int x, int y) const
+    {
+        return (double)DogAt<T, FROM_DOG>::at(tab, o, l, img + (size_t)y * pitch + x);
+    }
+};
+
+__device__ __forceinline__ bool inverse3d(const double *H, double *Hi)
+{
+#define HA(i, j) (H[(i) * 3 + (j)])
+    double A = HA(0, 0) * HA(1, 1) * HA(2, 2) + HA(0, 1) * HA(1, 2) * HA(2, 0) + HA(0, 2) * HA(1, 0) * HA(2, 1) -
+               HA(0, 0) * HA(1, 2) * HA(2, 1) - HA(0, 1) * HA(1, 0) * HA(2, 2) - HA(0, 2) * HA(1, 1) * HA(2, 0);
+    if (fabs(A) < 1e-10)
+        return false;
+    Hi[0] = HA(1, 1) * HA(2, 2) - HA(2, 1) * HA(1, 2);
+    Hi[1] = -(HA(0, 1) * HA(2, 2) - HA(2, 1) * HA(0, 2));
+    Hi[2] = HA(0, 1) * HA(1, 2) - HA(0, 2) * HA(1, 1);
+    Hi[3] = HA(1, 2) * HA(2, 0) - HA(2, 2) * HA(1, 0);
+    Hi[4] = -(HA(0, 2) * HA(2, 0) - HA(0, 0) * HA(2, 2));
+    Hi[5] = HA(0, 2) * HA(1, 0) - HA(0, 0) * HA(1, 2);
+    Hi[6] = HA(1, 0) * HA(2, 1) - HA(1, 1) * HA(2, 0);
+    Hi[7] = -(HA(0, 0) * HA(2, 1) - HA(0, 1) * HA(2, 0));
+    Hi[8] = HA(0, 0) * HA(1, 1) - HA(0, 1) * HA(1, 0);
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+        Hi[i] /= A;
+#undef HA
+    return true;
+}
+
+template <typename D>
+__device__ __forceinline__ void derivative3d(const D &g, int l, int x, int y, double *dx)
+{
+    dx[0] = (g.at(l, x + 1, y) - g.at(l, x - 1, y)) / 2.0;
+    dx[1] = (g.at(l, x, y + 1) - g.at(l, x, y - 1)) / 2.0;
+    dx[2] = (g.at(l + 1, x, y) - g.at(l - 1, x, y)) / 2.0;
+}
+
+template <typename D>
+__device__ __forceinline__ void offset3d(const D &g, int l, int x, int y, double *off)
+{
+    double val = g.at(l, x, y);
+    double Dxx = g.at(l, x + 1, y) + g.at(l, x - 1, y) - 2 * val;
+    double Dyy = g.at(l, x, y + 1) + g.at(l, x, y - 1) - 2 * val;
+    double Dss = g.at(l + 1, x, y) + g.at(l - 1, x, y) - 2 * val;
+    double Dxy = (g.at(l, x + 1, y + 1) + g.at(l, x - 1, y - 1) - g.at(l, x + 1, y - 1) - g.at(l, x - 1, y + 1)) / 4.0;
+    double Dxs = (g.at(l + 1, x + 1, y) + g.at(l - 1, x - 1, y) - g.at(l - 1, x + 1, y) - g.at(l + 1, x - 1, y)) / 4.0;
+    double Dys = (g.at(l + 1, x, y + 1) + g.at(l - 1, x, y - 1) - g.at(l + 1, x, y - 1) - g.at(l - 1, x, y + 1)) / 4.0;
+    double H[9] = {Dxx, Dxy, Dxs, Dxy, Dyy, Dys, Dxs, Dys, Dss};
+    double Hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // stays zero when the Hessian is singular (sift.cpp:778-780)
+    inverse3d(H, Hi);
+    double dx[3];
+    derivative3d(g, l, x, y, dx);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            a += Hi[i * 3 + j] * dx[j];
+        off[i] = -a;
+    }
+}
+
+template <typename T, bool FROM_DOG>
+__global__ __launch_bounds__(256) void refine_k(OctaveTab tab, const unsigned int *cand, size_t cand_img,
+                                                const unsigned int *cand_count, KpRec *kp, size_t kp_img,
+                                                unsigned long long *valid_words, size_t vw_img,
+                                                unsigned int *chunk_sums, size_t chunks_img,
+                                                unsigned long long *counters, double sigma, unsigned int cap)
+{
+    const int b = blockIdx.y;
+    const unsigned int n = min(cand_count[b], cap);
+    const int lane = threadIdx.x & 63;
+    unsigned int n2 = 0, n3 = 0;
+    // every wave handles 64 consecutive candidates per trip so that its ballot is one bitmap word
+    for (unsigned int c0 = (blockIdx.x * 256u + (threadIdx.x & ~63u)); c0 < n; c0 += gridDim.x * 256u) {
+        unsigned int c = c0 + lane;
+        bool ok = false, refined = false;
+        KpRec rec;
+        if (c < n) {
+            unsigned int v = cand[(size_t)b * cand_img + c];
+            unsigned int widx = v >> 6;
+            int bit = v & 63;
+            int o = 0;
+            while (o + 1 < tab.octaves && widx >= tab.wbase[o + 1])
+                o++;
+            unsigned int rem = widx - tab.wbase[o];
+            int nrows = tab.nrows[o], wpr = tab.wpr[o];
+            int layer = rem / (nrows * wpr) + 1;
+            rem -= (layer - 1) * nrows * wpr;
+            int y = rem / wpr + kBorder;
+            int x = (rem % wpr) * 64 + bit + kBorder;
+            const int rows = tab.rows[o], cols = tab.cols[o];
+            Dog3<T, FROM_DOG> g{tab, o, (size_t)b * tab.img_stride[o], tab.pitch[o]};
+
+            int interval = layer, l = layer;
+            double off[3] = {0, 0, 0};
+            int i = 0;
+            bool alive = true;
+            while (i < 5) { // MAX_INTERPOLATION_STEPS
+                offset3d(g, l, x, y, off);
+                if (fabs(off[0]) < 0.5 && fabs(off[1]) < 0.5 && fabs(off[2]) < 0.5)
+                    break;
+                // cvRound of an offset far outside int range always fails the range test below
+                if (!(fabs(off[0]) < 1.0e9) || !(fabs(off[1]) < 1.0e9) || !(fabs(off[2]) < 1.0e9)) {
+                    alive = false;
+                    break;
+                }
+                x += (int)rint(off[0]);
+                y += (int)rint(off[1]);
+                interval += (int)rint(off[2]);
+                l = interval; // idx = index - intvl + interval, as a level inside the octave
+                if (interval < 1 || interval > 3 || x >= cols - 1 || x < 2 || y >= rows - 1 || y < 2) {
+                    alive = false;
+                    break;
+                }
+                i++;
+            }
+            if (alive && i < 5) {
+                double dx[3];
+                derivative3d(g, l, x, y, dx);
+                double term = 0.0;
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    term += dx[q] * off[q];
+                double contrast = fabs(g.at(l, x, y) + 0.5 * term);
+                if (!(contrast < 0.03 / 3)) { // DXTHRESHOLD / INTERVALS
+                    refined = true;
+                    // passEdgeResponse on the ORIGINAL layer at the refined x,y (sift.cpp:960)
+                    double val = g.at(layer, x, y);
+                    double Dxx = g.at(layer, x + 1, y) + g.at(layer, x - 1, y) - 2 * val;
+                    double Dyy = g.at(layer, x, y + 1) + g.at(layer, x, y - 1) - 2 * val;
+                    double Dxy = (g.at(layer, x + 1, y + 1) + g.at(layer, x - 1, y - 1) - g.at(layer, x - 1, y + 1) -
+                                  g.at(layer, x + 1, y - 1)) / 4.0;
+                    double Tr = Dxx + Dyy;
+                    double Det = Dxx * Dyy - Dxy * Dxy;
+                    const double r = 10.0; // RATIO
+                    if (Det > 0 && Tr * Tr / Det < (r + 1) * (r + 1) / r) {
+                        ok = true;
+                        rec.x = x; rec.y = y; rec.octave = o; rec.interval = interval;
+                        rec.offx = off[0]; rec.offy = off[1]; rec.offi = off[2];
+                        double p2 = ldexp(1.0, o);
+                        rec.dx = ((x + off[0]) * p2) / 2;
+                        rec.dy = ((y + off[1]) * p2) / 2;
+                        double intvl = interval + off[2];
+                        rec.scale = (sigma * pow(2.0, o + intvl / 3)) / 2;
+                        rec.oscale = sigma * pow(2.0, intvl / 3);
+                        rec.val = val;
+                    }
+                }
+            }
+        }
+        unsigned long long m2 = __ballot(refined), m3 = __ballot(ok);
+        n2 += __popcll(m2);
+        n3 += __popcll(m3);
+        if (ok)
+            kp[(size_t)b * kp_img + c] = rec;
+        if (lane == 0) {
+            unsigned int widx = c0 >> 6;
+            valid_words[(size_t)b * vw_img + widx] = m3;
+            if (m3)
+                atomicAdd(&chunk_sums[(size_t)b * chunks_img + widx / kChunkWords], (unsigned int)__popcll(m3));
+        }
+    }
+    if (lane == 0 && (n2 | n3)) {
+        unsigned long long *ctr = counters + (size_t)b * 8;
+        atomicAdd(&ctr[3], (unsigned long long)n2);
+        atomicAdd(&ctr[4], (unsigned long long)n3);
+    }
+}
+
+void launch_refine(const OctaveTab &tab, const unsigned int *cand, size_t cand_img_stride,
+                   const unsigned int *cand_count, KpRec *kp, size_t kp_img_stride,
+                   unsigned long long *valid_words, size_t vw_img_stride, unsigned int *chunk_sums,
+                   size_t chunks_img_stride, unsigned long long *counters, double sigma, unsigned int cap, int B,
+                   int prec, hipStream_t s)
+{
+    unsigned int blocks = (cap + 255) / 256;
+    if (blocks > 512)
+        blocks = 512;
+    dim3 g(blocks, B);
+#define SG_REF(T, FD)                                                                                             \
+    refine_k<T, FD><<<g, 256, 0, s>>>(tab, cand, cand_img_stride, cand_count, kp, kp_img_stride, valid_words,     \
+                                      vw_img_stride, chunk_sums, chunks_img_stride, counters, sigma, cap)
+    bool fd = tab.from_dog != 0;
+    if (prec == SG_F64) { if (fd) SG_REF(double, true); else SG_REF(double, false); }
+    else { if (fd) SG_REF(float, true); else SG_REF(float, false); }
+#undef SG_REF
+}
+
+} // namespace sg

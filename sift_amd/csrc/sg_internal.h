@@ -1,0 +1,104 @@
+// sg_internal.h -- shared declarations of libsiftgpu's HIP sources (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "siftgpu.h"
+
+namespace sg {
+
+constexpr int kMaxOctaves = 16;
+constexpr int kLevels = 6;        // INTERVALS + 3 Gaussian levels per octave
+constexpr int kDogLevels = 5;     // INTERVALS + 2
+constexpr int kMaxFastRadius = 13;
+constexpr int kMaxTaps = 2 * kMaxFastRadius + 1;
+constexpr int kBorder = 5;        // IMG_BORDER, sift.h:58
+constexpr int kChunkWords = 1024; // bitmap words per compaction chunk
+constexpr int kOriBins = 36;
+
+// One image plane (or a batch of them): element pointer, geometry in elements.
+struct Plane {
+    void *p = nullptr;
+    int rows = 0, cols = 0, pitch = 0;
+    size_t img_stride = 0; // elements between images of a batch
+};
+
+// Filter taps handed to the blur kernels by value (zero-padded to 2*R+1 of the chosen kernel).
+template <typename T>
+struct Taps {
+    T k[kMaxTaps];
+};
+
+// Per-octave table handed to the keypoint kernels by value.
+struct OctaveTab {
+    const void *lv[kMaxOctaves][kLevels]; // Gaussian levels (or DoG levels 0..4 when from_dog)
+    int rows[kMaxOctaves], cols[kMaxOctaves], pitch[kMaxOctaves];
+    unsigned long long img_stride[kMaxOctaves];
+    unsigned int wbase[kMaxOctaves + 1]; // first bitmap word of each octave
+    int nrows[kMaxOctaves];              // scanned rows per layer = rows - 2*border (>= 0)
+    int wpr[kMaxOctaves];                // bitmap words per scanned row
+    int octaves;
+    int from_dog;
+};
+
+// Device keypoint record (after refinement): 80 bytes.
+struct KpRec {
+    int x, y, octave, interval;
+    double offx, offy, offi;
+    double dx, dy, scale, oscale, val;
+};
+
+// ---- image preparation -----------------------------------------------------------------
+void launch_gray(const uint8_t *src, int rows, int cols, int ch, size_t stride, size_t img_stride,
+                 const Plane &dst, int B, int prec, hipStream_t s);
+void launch_upsample(const Plane &src, const Plane &dst, int B, int prec, hipStream_t s);
+void launch_gray_upsample(const uint8_t *src, int rows, int cols, int ch, size_t stride, size_t img_stride,
+                          const Plane &dst, int B, int prec, hipStream_t s);
+void launch_downsample(const Plane &src, const Plane &dst, int B, int prec, hipStream_t s);
+void launch_sub(const Plane &a, const Plane &b, const Plane &c, int B, int prec, hipStream_t s);
+void launch_vnoise5(uint8_t *dst, int rows, int cols, uint64_t seed, hipStream_t s);
+
+// ---- blur ---------------------------------------------------------------------------------
+// taps: n doubles (host), n odd. Row pass src->tmp, column pass tmp->dst. In-place (src==dst) is allowed.
+void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
+void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
+
+// ---- detection --------------------------------------------------------------------------------
+void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words, size_t words_img_stride,
+                   unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
+                   double thresh, int nointerval, int prec, hipStream_t s);
+// exclusive scan of chunk_sums (n_chunks per image) in place; totals[b] = sum (clamped report of overflow)
+void launch_scan(unsigned int *chunk_sums, size_t chunks_img_stride, int n_chunks, unsigned int *totals,
+                 unsigned int cap, unsigned int *overflow, int B, hipStream_t s);
+// expand set bits of words (n_words per image) into out[b][pos] = word*64 + bit, ordered
+void launch_expand(const unsigned long long *words, size_t words_img_stride, unsigned int n_words,
+                   const unsigned int *dyn_items, unsigned int items_per_word, const unsigned int *chunk_offs,
+                   size_t chunks_img_stride, unsigned int *out,
+                   size_t out_img_stride, unsigned int cap, int B, hipStream_t s);
+void launch_refine(const OctaveTab &tab, const unsigned int *cand, size_t cand_img_stride,
+                   const unsigned int *cand_count, KpRec *kp, size_t kp_img_stride,
+                   unsigned long long *valid_words, size_t vw_img_stride, unsigned int *chunk_sums,
+                   size_t chunks_img_stride, unsigned long long *counters, double sigma, unsigned int cap, int B,
+                   int prec, hipStream_t s);
+
+// ---- orientation, descriptors, ordering ---------------------------------------------------------
+void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
+                   size_t src_img_stride, const unsigned int *kp_count, double *ori_tmp, size_t ori_img_stride,
+                   unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
+                   size_t chunks_img_stride, unsigned int cap, int B, int prec, hipStream_t s);
+void launch_descr(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
+                  size_t src_img_stride, const unsigned int *feat_src, size_t fsrc_img_stride,
+                  const unsigned int *feat_count, const double *ori_tmp, size_t ori_img_stride, uint8_t *desc,
+                  size_t desc_img_stride, double *prequant, size_t pq_img_stride, double *fscale,
+                  size_t fs_img_stride, unsigned int cap, int B, int prec, hipStream_t s);
+void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
+                 size_t rank_img_stride, unsigned int cap, int B, hipStream_t s);
+// mode 0: packed features (sg_packed_feature) at out + b*out_img_stride*144; mode 1: sg_keypoint records.
+void launch_pack(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src, size_t src_img_stride,
+                 const unsigned int *feat_src, size_t fsrc_img_stride, const unsigned int *feat_count,
+                 const double *ori_tmp, size_t ori_img_stride, const uint8_t *desc, size_t desc_img_stride,
+                 const unsigned int *rank, size_t rank_img_stride, void *out, size_t out_img_stride,
+                 unsigned int out_cap, unsigned int *out_counts, unsigned int *overflow, int mode, int sorted,
+                 unsigned int cap, int B, hipStream_t s);
+} // namespace sg

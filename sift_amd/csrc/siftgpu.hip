@@ -1,0 +1,1453 @@
+// siftgpu.hip -- context, launch sequence and the C ABI of libsiftgpu (see include/siftgpu.h).
+//
+// Launch sequence of one batch (reference sift/sift.cpp:1646-1707, Sift()):
+//   gray+upsample -> init blur -> per octave { decimate, 5 x (row pass, column pass), fused DoG+extrema scan }
+//   -> ordered compaction -> refine -> ordered compaction -> orientation -> ordered compaction
+//   -> descriptors -> rank by scale -> pack.
+// Everything is enqueued on the context's stream with fixed grids and device-side counts, so the host
+// never waits inside a batch.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "sg_internal.h"
+
+using namespace sg;
+
+static_assert(sizeof(sg_keypoint) == 1120, "sg_keypoint must match the reference's Keypoint layout");
+static_assert(sizeof(sg_packed_feature) == 144, "packed feature is 144 bytes");
+static_assert(sizeof(KpRec) == 80, "KpRec is 80 bytes");
+
+namespace {
+
+constexpr int kEventPairs = 1024;
+
+struct StageEvents {
+    hipEvent_t start[kEventPairs], stop[kEventPairs];
+    int stage[kEventPairs];
+    int used = 0;
+    bool created = false;
+};
+
+} // namespace
+
+struct sg_ctx {
+    sg_params prm;
+    hipStream_t stream = nullptr;
+    std::string err;
+    int B = 1;
+    size_t esize = 8;
+    unsigned int feat_cap = 0, cand_cap = 0;
+
+    // geometry of the current call
+    int w = 0, h = 0, octaves = 0, last_batch = 0;
+    int rows[kMaxOctaves], cols[kMaxOctaves], pitch[kMaxOctaves];
+    Plane level[kMaxOctaves][kLevels];
+    OctaveTab tab;
+    unsigned int n_words = 0;
+
+    // taps: [0] initial blur, [1..5] pyramid levels
+    double taps[kLevels][kMaxTaps];
+    int ntaps[kLevels];
+
+    // device buffers
+    uint8_t *d_in = nullptr;
+    size_t in_bytes = 0;
+    void *d_up = nullptr, *d_tmp = nullptr, *d_levels = nullptr;
+    size_t plane0_elems = 0, levels_elems = 0;
+    unsigned long long *d_words = nullptr, *d_vwords = nullptr, *d_pwords = nullptr;
+    size_t words_img = 0, vwords_img = 0, pwords_img = 0;
+    unsigned int *d_chunks = nullptr; // three arrays per image: detect, valid, peaks
+    size_t chunks1 = 0, chunks2 = 0, chunks3 = 0, chunks_total = 0;
+    unsigned int *d_cand = nullptr, *d_kpsrc = nullptr, *d_fsrc = nullptr, *d_rank = nullptr;
+    KpRec *d_kp = nullptr;
+    double *d_ori = nullptr, *d_pq = nullptr, *d_fscale = nullptr;
+    uint8_t *d_desc = nullptr;
+    unsigned int *d_counts = nullptr; // [3][B]: candidates, keypoints, features
+    unsigned long long *d_ctr = nullptr; // [B][8]
+    unsigned int *d_overflow = nullptr;  // [4]: candidates, keypoints, features, output
+    void *d_out = nullptr;
+    size_t out_bytes = 0;
+    unsigned int *d_outcounts = nullptr;
+
+    bool prof = false;
+    StageEvents ev;
+    double stage_ms[SG_ST_COUNT];
+    unsigned long long stage_launches[SG_ST_COUNT];
+};
+
+// ---------------------------------------------------------------------------------------- helpers
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            if (ctx)                                                                             \
+                (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                  \
+            return e_ == hipErrorOutOfMemory ? SG_E_NOMEM : SG_E_HIP;                            \
+        }                                                                                        \
+    } while (0)
+
+static int fail(sg_ctx *ctx, int code, const char *msg)
+{
+    if (ctx)
+        ctx->err = msg;
+    return code;
+}
+
+static int round_half_even(double v) { return (int)lrint(v); }
+
+// OpenCV GaussianBlur with Size(0,0) on a non-8-bit plane: ksize = cvRound(sigma*4*2+1)|1;
+// getGaussianKernel: exp(-0.5 x^2 / sigma^2) scaled by 1/sum.
+static int gaussian_taps(double sigma, double *k, int max_n)
+{
+    int n = round_half_even(sigma * 4 * 2 + 1) | 1;
+    if (n > max_n)
+        return -n;
+    double scale2x = -0.5 / (sigma * sigma);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        double t = exp(scale2x * x * x);
+        k[i] = t;
+        sum += t;
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++)
+        k[i] *= sum;
+    return n;
+}
+
+// reference sift/sift.cpp:1653
+static int num_octaves(int base_rows, int base_cols)
+{
+    int m = std::min(base_rows, base_cols);
+    int o = (int)(log((double)m) / log(2.0) - 2);
+    return o;
+}
+
+static int pitch_of(int cols) { return (cols + 3) & ~3; }
+
+struct Geometry {
+    int octaves;
+    int rows[kMaxOctaves], cols[kMaxOctaves], pitch[kMaxOctaves];
+    unsigned int wbase[kMaxOctaves + 1];
+    int nrows[kMaxOctaves], wpr[kMaxOctaves];
+};
+
+static int make_geometry(int base_rows, int base_cols, int octaves, Geometry *g)
+{
+    if (octaves < 0)
+        octaves = 0;
+    if (octaves > kMaxOctaves)
+        return SG_E_UNSUPPORTED;
+    g->octaves = octaves;
+    unsigned int wb = 0;
+    for (int o = 0; o < octaves; o++) {
+        if (o == 0) {
+            g->rows[0] = base_rows;
+            g->cols[0] = base_cols;
+        } else if (g->rows[o - 1] <= 1 || g->cols[o - 1] <= 1) {
+            g->rows[o] = g->rows[o - 1];
+            g->cols[o] = g->cols[o - 1];
+        } else {
+            g->rows[o] = g->rows[o - 1] / 2;
+            g->cols[o] = g->cols[o - 1] / 2;
+        }
+        g->pitch[o] = pitch_of(g->cols[o]);
+        int nr = g->rows[o] - 2 * kBorder, nc = g->cols[o] - 2 * kBorder;
+        g->nrows[o] = nr > 0 && nc > 0 ? nr : 0;
+        g->wpr[o] = nr > 0 && nc > 0 ? (nc + 63) / 64 : 0;
+        g->wbase[o] = wb;
+        wb += 3u * (unsigned int)g->nrows[o] * (unsigned int)g->wpr[o];
+    }
+    g->wbase[octaves] = wb;
+    for (int o = octaves + 1; o <= kMaxOctaves; o++)
+        g->wbase[o] = wb;
+    return SG_OK;
+}
+
+static size_t levels_elems_for(const Geometry &g, int B)
+{
+    size_t total = 0;
+    for (int o = 0; o < g.octaves; o++)
+        total += (size_t)kLevels * B * ((size_t)g.rows[o] * g.pitch[o] + 64);
+    return total;
+}
+
+// ---- profiling events -----------------------------------------------------------------------------
+
+static void flush_events(sg_ctx *c)
+{
+    if (!c->ev.used)
+        return;
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < c->ev.used; i++) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->ev.start[i], c->ev.stop[i]) == hipSuccess) {
+            c->stage_ms[c->ev.stage[i]] += ms;
+        }
+    }
+    c->ev.used = 0;
+}
+
+struct StageScope {
+    sg_ctx *c;
+    int idx = -1;
+    StageScope(sg_ctx *ctx, int stage, int launches = 1) : c(ctx)
+    {
+        if (!c->prof)
+            return;
+        if (c->ev.used == kEventPairs)
+            flush_events(c);
+        idx = c->ev.used++;
+        c->ev.stage[idx] = stage;
+        c->stage_launches[stage] += launches;
+        (void)hipEventRecord(c->ev.start[idx], c->stream);
+    }
+    ~StageScope()
+    {
+        if (idx >= 0)
+            (void)hipEventRecord(c->ev.stop[idx], c->stream);
+    }
+};
+
+// ---- geometry / tables ------------------------------------------------------------------------------
+
+static int set_geometry(sg_ctx *c, int w, int h, int B)
+{
+    if (w < 2 || h < 2)
+        return fail(c, SG_E_INVALID, "image must be at least 2x2");
+    if (w > c->prm.max_width || h > c->prm.max_height)
+        return fail(c, SG_E_CAPACITY, "image larger than the context's max_width/max_height");
+    if (B < 1 || B > c->B)
+        return fail(c, SG_E_CAPACITY, "batch larger than the context's max_batch");
+    Geometry g;
+    int oct = num_octaves(2 * h, 2 * w);
+    int rc = make_geometry(2 * h, 2 * w, oct, &g);
+    if (rc != SG_OK)
+        return fail(c, rc, "too many octaves");
+    if (levels_elems_for(g, B) > c->levels_elems || g.wbase[g.octaves] > c->words_img)
+        return fail(c, SG_E_CAPACITY, "pyramid does not fit the context's buffers");
+    c->w = w;
+    c->h = h;
+    c->octaves = g.octaves;
+    c->last_batch = B;
+    memset(&c->tab, 0, sizeof(c->tab));
+    size_t off = 0;
+    for (int o = 0; o < g.octaves; o++) {
+        c->rows[o] = g.rows[o];
+        c->cols[o] = g.cols[o];
+        c->pitch[o] = g.pitch[o];
+        size_t img = (size_t)g.rows[o] * g.pitch[o] + 64;
+        img = (img + 63) & ~(size_t)63;
+        for (int l = 0; l < kLevels; l++) {
+            Plane &p = c->level[o][l];
+            p.p = (char *)c->d_levels + off * c->esize;
+            p.rows = g.rows[o];
+            p.cols = g.cols[o];
+            p.pitch = g.pitch[o];
+            p.img_stride = img;
+            off += img * B;
+            c->tab.lv[o][l] = p.p;
+        }
+        c->tab.rows[o] = g.rows[o];
+        c->tab.cols[o] = g.cols[o];
+        c->tab.pitch[o] = g.pitch[o];
+        c->tab.img_stride[o] = img;
+        c->tab.nrows[o] = g.nrows[o];
+        c->tab.wpr[o] = g.wpr[o];
+    }
+    for (int o = 0; o <= kMaxOctaves; o++)
+        c->tab.wbase[o] = g.wbase[o];
+    c->tab.octaves = g.octaves;
+    c->tab.from_dog = 0;
+    c->n_words = g.wbase[g.octaves];
+    return SG_OK;
+}
+
+// ---- keypoint stages (shared by the whole path and the stage entry points) ------------------------------
+
+static void detect_phase(sg_ctx *c, const OctaveTab &tab, unsigned int n_words, int B, int nointerval)
+{
+    hipStream_t s = c->stream;
+    const int prec = c->prm.precision;
+    (void)hipMemsetAsync(c->d_chunks, 0, sizeof(unsigned int) * c->chunks_total * c->B, s);
+    (void)hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long) * 8 * c->B, s);
+    (void)hipMemsetAsync(c->d_counts, 0, sizeof(unsigned int) * 3 * c->B, s);
+    unsigned int *ch1 = c->d_chunks, *ch2 = c->d_chunks + c->chunks1, *ch3 = ch2 + c->chunks2;
+    (void)ch3;
+    const double thresh = 0.5 * 0.03 / 3; // 0.5 * DXTHRESHOLD / intervals (sift.cpp:924)
+    {
+        StageScope sc(c, SG_ST_DETECT, tab.octaves);
+        for (int o = 0; o < tab.octaves; o++)
+            launch_detect(tab, o, B, c->d_words, c->words_img, ch1, c->chunks_total, c->d_ctr, thresh, nointerval, prec, s);
+    }
+    unsigned int *n_cand = c->d_counts, *n_kp = c->d_counts + c->B;
+    {
+        StageScope sc(c, SG_ST_COMPACT, 2);
+        int nch = (int)((n_words + kChunkWords - 1) / kChunkWords);
+        launch_scan(ch1, c->chunks_total, nch, n_cand, c->cand_cap, c->d_overflow + 0, B, s);
+        launch_expand(c->d_words, c->words_img, n_words, nullptr, 64, ch1, c->chunks_total, c->d_cand, c->cand_cap,
+                      c->cand_cap, B, s);
+    }
+    {
+        StageScope sc(c, SG_ST_REFINE);
+        launch_refine(tab, c->d_cand, c->cand_cap, n_cand, c->d_kp, c->cand_cap, c->d_vwords, c->vwords_img, ch2,
+                      c->chunks_total, c->d_ctr, c->prm.sigma, c->cand_cap, B, prec, s);
+    }
+    {
+        StageScope sc(c, SG_ST_COMPACT, 2);
+        launch_scan(ch2, c->chunks_total, (int)c->chunks2, n_kp, c->feat_cap, c->d_overflow + 1, B, s);
+        launch_expand(c->d_vwords, c->vwords_img, (unsigned int)c->vwords_img, n_cand, 64, ch2, c->chunks_total,
+                      c->d_kpsrc, c->feat_cap, c->feat_cap, B, s);
+    }
+}
+
+static void orient_phase(sg_ctx *c, const OctaveTab &tab, int B)
+{
+    hipStream_t s = c->stream;
+    unsigned int *ch3 = c->d_chunks + c->chunks1 + c->chunks2;
+    unsigned int *n_kp = c->d_counts + c->B, *n_feat = c->d_counts + 2 * c->B;
+    {
+        StageScope sc(c, SG_ST_ORIENT);
+        launch_orient(tab, c->d_kp, c->cand_cap, c->d_kpsrc, c->feat_cap, n_kp, c->d_ori, (size_t)c->feat_cap * kOriBins,
+                      c->d_pwords, c->pwords_img, ch3, c->chunks_total, c->feat_cap, B, c->prm.precision, s);
+    }
+    {
+        StageScope sc(c, SG_ST_COMPACT, 2);
+        launch_scan(ch3, c->chunks_total, (int)c->chunks3, n_feat, c->feat_cap, c->d_overflow + 2, B, s);
+        // one word per keypoint
+        launch_expand(c->d_pwords, c->pwords_img, (unsigned int)c->pwords_img, n_kp, 1, ch3, c->chunks_total, c->d_fsrc,
+                      c->feat_cap, c->feat_cap, B, s);
+    }
+}
+
+static void descr_phase(sg_ctx *c, const OctaveTab &tab, int B)
+{
+    hipStream_t s = c->stream;
+    unsigned int *n_feat = c->d_counts + 2 * c->B;
+    {
+        StageScope sc(c, SG_ST_DESCR);
+        launch_descr(tab, c->d_kp, c->cand_cap, c->d_kpsrc, c->feat_cap, c->d_fsrc, c->feat_cap, n_feat, c->d_ori,
+                     (size_t)c->feat_cap * kOriBins, c->d_desc, (size_t)c->feat_cap * 128, c->d_pq,
+                     (size_t)c->feat_cap * 128, c->d_fscale, c->feat_cap, c->feat_cap, B, c->prm.precision, s);
+    }
+}
+
+static void rank_phase(sg_ctx *c, int B)
+{
+    unsigned int *n_feat = c->d_counts + 2 * c->B;
+    StageScope sc(c, SG_ST_SORT);
+    launch_rank(c->d_fscale, c->feat_cap, n_feat, c->d_rank, c->feat_cap, c->feat_cap, B, c->stream);
+}
+
+static void pack_phase(sg_ctx *c, void *out, size_t out_img_stride, unsigned int out_cap, unsigned int *out_counts,
+                       int mode, int sorted, int B)
+{
+    unsigned int *n_feat = c->d_counts + 2 * c->B;
+    StageScope sc(c, SG_ST_SORT);
+    launch_pack(c->d_kp, c->cand_cap, c->d_kpsrc, c->feat_cap, c->d_fsrc, c->feat_cap, n_feat, c->d_ori,
+                (size_t)c->feat_cap * kOriBins, c->d_desc, (size_t)c->feat_cap * 128, c->d_rank, c->feat_cap, out,
+                out_img_stride, out_cap, out_counts, c->d_overflow + 3, mode, sorted, c->feat_cap, B, c->stream);
+}
+
+// blur src -> dst through the context's row-pass scratch plane
+static void blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, const double *taps, int n)
+{
+    Plane tmp = src;
+    tmp.p = c->d_tmp;
+    tmp.pitch = src.pitch;
+    tmp.img_stride = (size_t)src.rows * src.pitch;
+    {
+        StageScope sc(c, SG_ST_BLUR_ROW);
+        launch_blur_row(src, tmp, B, taps, n, c->prm.precision, c->stream);
+    }
+    {
+        StageScope sc(c, SG_ST_BLUR_COL);
+        launch_blur_col(tmp, dst, B, taps, n, c->prm.precision, c->stream);
+    }
+}
+
+static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, int ch, size_t stride, size_t img_stride)
+{
+    int rc = set_geometry(c, w, h, B);
+    if (rc != SG_OK)
+        return rc;
+    if (ch < 3)
+        return fail(c, SG_E_INVALID, "input needs at least 3 interleaved channels (b,g,r)");
+    hipStream_t s = c->stream;
+    const int prec = c->prm.precision;
+    (void)hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int) * 4, s);
+    if (c->octaves == 0) {
+        (void)hipMemsetAsync(c->d_counts, 0, sizeof(unsigned int) * 3 * c->B, s);
+        (void)hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long) * 8 * c->B, s);
+        return SG_OK;
+    }
+    Plane up;
+    up.p = c->d_up;
+    up.rows = 2 * h;
+    up.cols = 2 * w;
+    up.pitch = pitch_of(2 * w);
+    up.img_stride = (size_t)up.rows * up.pitch;
+    {
+        StageScope sc(c, SG_ST_PREP);
+        launch_gray_upsample(d_imgs, h, w, ch, stride, img_stride, up, B, prec, s);
+    }
+    blur_planes(c, up, c->level[0][0], B, c->taps[0], c->ntaps[0]);
+    for (int o = 0; o < c->octaves; o++) {
+        if (o > 0) {
+            StageScope sc(c, SG_ST_DOWNSAMPLE);
+            if (c->rows[o] == c->rows[o - 1]) // a dimension <= 1: DownSample copies (sift.cpp:64-68)
+                (void)hipMemcpyAsync(c->level[o][0].p, c->level[o - 1][3].p,
+                                     c->esize * c->level[o][0].img_stride * B, hipMemcpyDeviceToDevice, s);
+            else
+                launch_downsample(c->level[o - 1][3], c->level[o][0], B, prec, s);
+        }
+        for (int l = 1; l < kLevels; l++)
+            blur_planes(c, c->level[o][l - 1], c->level[o][l], B, c->taps[l], c->ntaps[l]);
+    }
+    detect_phase(c, c->tab, c->n_words, B, c->prm.nointerval);
+    orient_phase(c, c->tab, B);
+    descr_phase(c, c->tab, B);
+    rank_phase(c, B);
+    HIPCHK(c, hipGetLastError());
+    return SG_OK;
+}
+
+static int check_overflow(sg_ctx *c)
+{
+    unsigned int ov[4];
+    HIPCHK(c, hipMemcpyAsync(ov, c->d_overflow, sizeof ov, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (ov[0] || ov[1] || ov[2] || ov[3]) {
+        char buf[256];
+        snprintf(buf, sizeof buf,
+                 "capacity exceeded: candidates %u (cap %u), keypoints %u, features %u (cap %u), output %u",
+                 ov[0], c->cand_cap, ov[1], ov[2], c->feat_cap, ov[3]);
+        c->err = buf;
+        return SG_E_CAPACITY;
+    }
+    return SG_OK;
+}
+
+static int ensure_in(sg_ctx *c, size_t bytes)
+{
+    if (bytes <= c->in_bytes)
+        return SG_OK;
+    if (c->d_in)
+        (void)hipFree(c->d_in);
+    c->d_in = nullptr;
+    c->in_bytes = 0;
+    HIPCHK(c, hipMalloc((void **)&c->d_in, bytes));
+    c->in_bytes = bytes;
+    return SG_OK;
+}
+
+static int ensure_out(sg_ctx *c, size_t bytes)
+{
+    if (bytes <= c->out_bytes)
+        return SG_OK;
+    if (c->d_out)
+        (void)hipFree(c->d_out);
+    c->d_out = nullptr;
+    c->out_bytes = 0;
+    HIPCHK(c, hipMalloc(&c->d_out, bytes));
+    c->out_bytes = bytes;
+    return SG_OK;
+}
+
+// =========================================================================================== C ABI
+
+extern "C" {
+
+void sg_default_params(sg_params *p)
+{
+    if (!p)
+        return;
+    memset(p, 0, sizeof *p);
+    p->sigma = 1.6;
+    p->intervals = 3;
+    p->precision = SG_F64;
+    p->nointerval = 0;
+    p->max_width = 1920;
+    p->max_height = 1080;
+    p->max_batch = 1;
+    p->max_features = 0;
+    p->device = 0;
+    p->verbose = 0;
+    p->keep_prequant = 0;
+}
+
+const char *sg_strerror(int status)
+{
+    switch (status) {
+    case SG_OK: return "ok";
+    case SG_E_INVALID: return "invalid argument";
+    case SG_E_HIP: return "HIP runtime error";
+    case SG_E_CAPACITY: return "capacity exceeded";
+    case SG_E_UNSUPPORTED: return "unsupported parameter";
+    case SG_E_NOMEM: return "out of memory";
+    default: return "unknown status";
+    }
+}
+
+const char *sg_last_error(const sg_ctx *ctx) { return ctx ? ctx->err.c_str() : ""; }
+
+int sg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+        return 0;
+    return n;
+}
+
+int sg_destroy(sg_ctx *c)
+{
+    if (!c)
+        return SG_OK;
+    (void)hipSetDevice(c->prm.device);
+    if (c->stream)
+        (void)hipStreamSynchronize(c->stream);
+    void *bufs[] = {c->d_in, c->d_up, c->d_tmp, c->d_levels, c->d_words, c->d_vwords, c->d_pwords, c->d_chunks,
+                    c->d_cand, c->d_kpsrc, c->d_fsrc, c->d_rank, c->d_kp, c->d_ori, c->d_pq, c->d_fscale, c->d_desc,
+                    c->d_counts, c->d_ctr, c->d_overflow, c->d_out, c->d_outcounts};
+    for (void *b : bufs)
+        if (b)
+            (void)hipFree(b);
+    if (c->ev.created)
+        for (int i = 0; i < kEventPairs; i++) {
+            (void)hipEventDestroy(c->ev.start[i]);
+            (void)hipEventDestroy(c->ev.stop[i]);
+        }
+    if (c->stream)
+        (void)hipStreamDestroy(c->stream);
+    delete c;
+    return SG_OK;
+}
+
+int sg_create(const sg_params *p, sg_ctx **out)
+{
+    if (!p || !out)
+        return SG_E_INVALID;
+    *out = nullptr;
+    if (p->intervals != 3)
+        return SG_E_UNSUPPORTED;
+    if (!(p->sigma > 1.0) || p->max_width < 2 || p->max_height < 2 || p->max_batch < 1)
+        return SG_E_INVALID; // sigma <= 2*INIT_SIGMA makes the initial blur's sigma imaginary (sift.cpp:343)
+    if (p->precision != SG_F64 && p->precision != SG_F32)
+        return SG_E_INVALID;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev)
+        return SG_E_HIP;
+    if (hipSetDevice(p->device) != hipSuccess)
+        return SG_E_HIP;
+    sg_ctx *c = new sg_ctx;
+    c->prm = *p;
+    c->B = p->max_batch;
+    c->esize = p->precision == SG_F64 ? 8 : 4;
+    memset(c->stage_ms, 0, sizeof c->stage_ms);
+    memset(c->stage_launches, 0, sizeof c->stage_launches);
+
+    // taps: initial blur sigma (sift.cpp:343) and the pyramid's incremental sigmas (sift.cpp:361-372)
+    double sig[kLevels];
+    sig[0] = sqrt(p->sigma * p->sigma - (0.5 * 2) * (0.5 * 2));
+    {
+        double k = pow(2.0, 1.0 / p->intervals);
+        for (int i = 1; i < kLevels; i++) {
+            double sig_prev = pow(k, i - 1) * p->sigma;
+            double sig_total = sig_prev * k;
+            sig[i] = sqrt(sig_total * sig_total - sig_prev * sig_prev);
+        }
+    }
+    for (int i = 0; i < kLevels; i++) {
+        c->ntaps[i] = gaussian_taps(sig[i], c->taps[i], kMaxTaps);
+        if (c->ntaps[i] < 0) {
+            delete c;
+            return SG_E_UNSUPPORTED; // sigma so large that a pyramid blur exceeds the fast kernels' radius
+        }
+    }
+
+    const int W = p->max_width, H = p->max_height, B = c->B;
+    size_t px = (size_t)W * H;
+    c->feat_cap = p->max_features > 0 ? (unsigned int)p->max_features : (unsigned int)(px / 40 + 4096);
+    c->cand_cap = 3 * c->feat_cap + 4096;
+    c->cand_cap = (c->cand_cap + 63) & ~63u;
+
+    Geometry g;
+    int rc = make_geometry(2 * H, 2 * W, std::max(0, num_octaves(2 * H, 2 * W)), &g);
+    if (rc != SG_OK) {
+        delete c;
+        return rc;
+    }
+    // a smaller image can have pitch padding that a max-size layout lacks: keep a margin
+    c->levels_elems = levels_elems_for(g, B) + (size_t)kLevels * kMaxOctaves * B * 256;
+    c->plane0_elems = (size_t)(2 * H) * pitch_of(2 * W) + 64;
+    c->words_img = g.wbase[g.octaves] + 2048;
+    c->vwords_img = c->cand_cap / 64;
+    c->pwords_img = c->feat_cap;
+    c->chunks1 = (c->words_img + kChunkWords - 1) / kChunkWords + 1;
+    c->chunks2 = (c->vwords_img + kChunkWords - 1) / kChunkWords + 1;
+    c->chunks3 = (c->pwords_img + kChunkWords - 1) / kChunkWords + 1;
+    c->chunks_total = c->chunks1 + c->chunks2 + c->chunks3;
+
+#define ALLOC(ptr, bytes)                                                  \
+    do {                                                                   \
+        hipError_t e_ = hipMalloc((void **)&(ptr), (bytes));               \
+        if (e_ != hipSuccess) {                                            \
+            sg_destroy(c);                                                 \
+            return e_ == hipErrorOutOfMemory ? SG_E_NOMEM : SG_E_HIP;      \
+        }                                                                  \
+    } while (0)
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SG_E_HIP;
+    }
+    ALLOC(c->d_up, c->esize * c->plane0_elems * B);
+    ALLOC(c->d_tmp, c->esize * c->plane0_elems * B);
+    ALLOC(c->d_levels, c->esize * c->levels_elems);
+    ALLOC(c->d_words, sizeof(unsigned long long) * c->words_img * B);
+    ALLOC(c->d_vwords, sizeof(unsigned long long) * c->vwords_img * B);
+    ALLOC(c->d_pwords, sizeof(unsigned long long) * c->pwords_img * B);
+    ALLOC(c->d_chunks, sizeof(unsigned int) * c->chunks_total * B);
+    ALLOC(c->d_cand, sizeof(unsigned int) * (size_t)c->cand_cap * B);
+    ALLOC(c->d_kp, sizeof(KpRec) * (size_t)c->cand_cap * B);
+    ALLOC(c->d_kpsrc, sizeof(unsigned int) * (size_t)c->feat_cap * B);
+    ALLOC(c->d_fsrc, sizeof(unsigned int) * (size_t)c->feat_cap * B);
+    ALLOC(c->d_rank, sizeof(unsigned int) * (size_t)c->feat_cap * B);
+    ALLOC(c->d_ori, sizeof(double) * (size_t)c->feat_cap * kOriBins * B);
+    ALLOC(c->d_fscale, sizeof(double) * (size_t)c->feat_cap * B);
+    ALLOC(c->d_desc, (size_t)c->feat_cap * 128 * B);
+    if (p->keep_prequant)
+        ALLOC(c->d_pq, sizeof(double) * (size_t)c->feat_cap * 128 * B);
+    ALLOC(c->d_counts, sizeof(unsigned int) * 3 * B);
+    ALLOC(c->d_ctr, sizeof(unsigned long long) * 8 * B);
+    ALLOC(c->d_overflow, sizeof(unsigned int) * 4);
+    ALLOC(c->d_outcounts, sizeof(unsigned int) * B);
+#undef ALLOC
+    (void)hipMemset(c->d_words, 0, sizeof(unsigned long long) * c->words_img * B);
+    (void)hipMemset(c->d_vwords, 0, sizeof(unsigned long long) * c->vwords_img * B);
+    (void)hipMemset(c->d_pwords, 0, sizeof(unsigned long long) * c->pwords_img * B);
+    (void)hipMemset(c->d_counts, 0, sizeof(unsigned int) * 3 * B);
+    (void)hipMemset(c->d_overflow, 0, sizeof(unsigned int) * 4);
+    (void)hipDeviceSynchronize();
+    *out = c;
+    return SG_OK;
+}
+
+int sg_sync(sg_ctx *c)
+{
+    if (!c)
+        return SG_E_INVALID;
+    return check_overflow(c);
+}
+
+// ---- whole path ---------------------------------------------------------------------------------------
+
+int sg_extract_batch_device(sg_ctx *c, const uint8_t *d_imgs, int n_img, int width, int height, int channels,
+                            size_t stride, size_t img_stride, sg_packed_feature *d_out, size_t cap_per_image,
+                            uint32_t *d_counts)
+{
+    if (!c || !d_imgs || !d_out || !d_counts || n_img < 1)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    int rc = run_pipeline(c, d_imgs, n_img, width, height, channels, stride, img_stride);
+    if (rc != SG_OK)
+        return rc;
+    unsigned int cap = cap_per_image > 0xffffffffu ? 0xffffffffu : (unsigned int)cap_per_image;
+    pack_phase(c, d_out, cap_per_image, cap, d_counts, 0, 1, n_img);
+    HIPCHK(c, hipGetLastError());
+    return SG_OK;
+}
+
+int sg_extract_batch(sg_ctx *c, const uint8_t *const *imgs, int n_img, int width, int height, int channels,
+                     size_t stride, sg_packed_feature *out, size_t cap_per_image, uint32_t *counts)
+{
+    if (!c || !imgs || !out || !counts || n_img < 1 || n_img > c->B)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    size_t img_bytes = stride * (size_t)height;
+    int rc = ensure_in(c, img_bytes * n_img);
+    if (rc != SG_OK)
+        return rc;
+    rc = ensure_out(c, sizeof(sg_packed_feature) * cap_per_image * n_img);
+    if (rc != SG_OK)
+        return rc;
+    for (int i = 0; i < n_img; i++)
+        HIPCHK(c, hipMemcpyAsync(c->d_in + img_bytes * i, imgs[i], img_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = sg_extract_batch_device(c, c->d_in, n_img, width, height, channels, stride, img_bytes,
+                                 (sg_packed_feature *)c->d_out, cap_per_image, c->d_outcounts);
+    if (rc != SG_OK)
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(counts, c->d_outcounts, sizeof(uint32_t) * n_img, hipMemcpyDeviceToHost, c->stream));
+    rc = check_overflow(c);
+    if (rc != SG_OK)
+        return rc;
+    for (int i = 0; i < n_img; i++)
+        HIPCHK(c, hipMemcpyAsync(out + cap_per_image * i, (sg_packed_feature *)c->d_out + cap_per_image * i,
+                                 sizeof(sg_packed_feature) * counts[i], hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SG_OK;
+}
+
+int sg_extract(sg_ctx *c, const uint8_t *px, int width, int height, int channels, size_t stride, sg_keypoint *out,
+               size_t cap, size_t *n)
+{
+    if (!c || !px || !n || (cap && !out))
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    size_t img_bytes = stride * (size_t)height;
+    int rc = ensure_in(c, img_bytes);
+    if (rc != SG_OK)
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, px, img_bytes, hipMemcpyHostToDevice, c->stream));
+    rc = run_pipeline(c, c->d_in, 1, width, height, channels, stride, img_bytes);
+    if (rc != SG_OK)
+        return rc;
+    unsigned int nf = 0;
+    HIPCHK(c, hipMemcpyAsync(&nf, c->d_counts + 2 * c->B, sizeof nf, hipMemcpyDeviceToHost, c->stream));
+    rc = check_overflow(c); // synchronises
+    if (rc != SG_OK)
+        return rc;
+    *n = nf;
+    if (nf > cap)
+        return fail(c, SG_E_CAPACITY, "output array too small");
+    if (nf == 0)
+        return SG_OK;
+    rc = ensure_out(c, sizeof(sg_keypoint) * (size_t)nf);
+    if (rc != SG_OK)
+        return rc;
+    pack_phase(c, c->d_out, nf, nf, nullptr, 1, 1, 1);
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out, sizeof(sg_keypoint) * (size_t)nf, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SG_OK;
+}
+
+// ---- inspection -------------------------------------------------------------------------------------------
+
+int sg_last_octaves(const sg_ctx *c) { return c ? c->octaves : 0; }
+
+int sg_level_dims(const sg_ctx *c, int octave, int *rows, int *cols)
+{
+    if (!c || octave < 0 || octave >= c->octaves)
+        return SG_E_INVALID;
+    if (rows)
+        *rows = c->rows[octave];
+    if (cols)
+        *cols = c->cols[octave];
+    return SG_OK;
+}
+
+static int download_plane(sg_ctx *c, const Plane &p, int image, double *dst)
+{
+    const size_t n = (size_t)p.rows * p.pitch;
+    std::vector<unsigned char> host(n * c->esize);
+    HIPCHK(c, hipMemcpyAsync(host.data(), (const char *)p.p + (size_t)image * p.img_stride * c->esize, n * c->esize,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int y = 0; y < p.rows; y++)
+        for (int x = 0; x < p.cols; x++)
+            dst[(size_t)y * p.cols + x] = c->esize == 8 ? ((const double *)host.data())[(size_t)y * p.pitch + x]
+                                                        : (double)((const float *)host.data())[(size_t)y * p.pitch + x];
+    return SG_OK;
+}
+
+int sg_read_level(sg_ctx *c, int image, int octave, int level, double *dst)
+{
+    if (!c || !dst || octave < 0 || octave >= c->octaves || level < 0 || level >= kLevels || image < 0 ||
+        image >= c->last_batch)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    return download_plane(c, c->level[octave][level], image, dst);
+}
+
+int sg_read_counters(sg_ctx *c, int image, sg_counters *out)
+{
+    if (!c || !out || image < 0 || image >= c->B)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    unsigned long long v[8];
+    HIPCHK(c, hipMemcpyAsync(v, c->d_ctr + 8 * image, sizeof v, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    out->cc00 = v[0]; out->cc0 = v[1]; out->cc1 = v[2]; out->cc2 = v[3]; out->cc3 = v[4];
+    return SG_OK;
+}
+
+static void kprec_to_keypoint(const KpRec &r, sg_keypoint *k)
+{
+    memset(k, 0, sizeof *k);
+    k->octave = r.octave; k->interval = r.interval; k->offset_interval = r.offi;
+    k->x = r.x; k->y = r.y; k->scale = r.scale; k->dx = r.dx; k->dy = r.dy;
+    k->offset_x = r.offx; k->offset_y = r.offy; k->octave_scale = r.oscale; k->val = r.val;
+}
+
+static void keypoint_to_kprec(const sg_keypoint &k, KpRec *r)
+{
+    r->x = k.x; r->y = k.y; r->octave = k.octave; r->interval = k.interval;
+    r->offx = k.offset_x; r->offy = k.offset_y; r->offi = k.offset_interval;
+    r->dx = k.dx; r->dy = k.dy; r->scale = k.scale; r->oscale = k.octave_scale; r->val = k.val;
+}
+
+static int download_keypoints(sg_ctx *c, int image, std::vector<KpRec> *recs)
+{
+    unsigned int nk = 0;
+    HIPCHK(c, hipMemcpyAsync(&nk, c->d_counts + c->B + image, sizeof nk, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    recs->resize(nk);
+    if (!nk)
+        return SG_OK;
+    std::vector<unsigned int> src(nk);
+    HIPCHK(c, hipMemcpyAsync(src.data(), c->d_kpsrc + (size_t)image * c->feat_cap, sizeof(unsigned int) * nk,
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned int hi = *std::max_element(src.begin(), src.end());
+    std::vector<KpRec> all(hi + 1);
+    HIPCHK(c, hipMemcpyAsync(all.data(), c->d_kp + (size_t)image * c->cand_cap, sizeof(KpRec) * (hi + 1),
+                             hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (unsigned int i = 0; i < nk; i++)
+        (*recs)[i] = all[src[i]];
+    return SG_OK;
+}
+
+int sg_read_keypoints(sg_ctx *c, int image, sg_keypoint *out, size_t cap, size_t *n)
+{
+    if (!c || !n || image < 0 || image >= c->B)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    std::vector<KpRec> recs;
+    int rc = download_keypoints(c, image, &recs);
+    if (rc != SG_OK)
+        return rc;
+    *n = recs.size();
+    if (recs.size() > cap)
+        return SG_E_CAPACITY;
+    for (size_t i = 0; i < recs.size(); i++)
+        kprec_to_keypoint(recs[i], &out[i]);
+    return SG_OK;
+}
+
+int sg_read_features_unsorted(sg_ctx *c, int image, sg_keypoint *out, size_t cap, size_t *n, double *prequant)
+{
+    if (!c || !n || image < 0 || image >= c->B)
+        return SG_E_INVALID;
+    if (prequant && !c->d_pq)
+        return fail(c, SG_E_INVALID, "context was created without keep_prequant");
+    (void)hipSetDevice(c->prm.device);
+    unsigned int nf = 0;
+    HIPCHK(c, hipMemcpyAsync(&nf, c->d_counts + 2 * c->B + image, sizeof nf, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    *n = nf;
+    if (nf > cap)
+        return SG_E_CAPACITY;
+    if (!nf)
+        return SG_OK;
+    int rc = ensure_out(c, sizeof(sg_keypoint) * (size_t)nf);
+    if (rc != SG_OK)
+        return rc;
+    // pack image `image` alone, unsorted: shift every per-image base by hand
+    {
+        size_t b = (size_t)image;
+        launch_pack(c->d_kp + b * c->cand_cap, 0, c->d_kpsrc + b * c->feat_cap, 0, c->d_fsrc + b * c->feat_cap, 0,
+                    c->d_counts + 2 * c->B + image, c->d_ori + b * c->feat_cap * kOriBins, 0,
+                    c->d_desc + b * c->feat_cap * 128, 0, c->d_rank + b * c->feat_cap, 0, c->d_out, 0, nf, nullptr,
+                    c->d_overflow + 3, 1, 0, c->feat_cap, 1, c->stream);
+    }
+    HIPCHK(c, hipMemcpyAsync(out, c->d_out, sizeof(sg_keypoint) * (size_t)nf, hipMemcpyDeviceToHost, c->stream));
+    if (prequant)
+        HIPCHK(c, hipMemcpyAsync(prequant, c->d_pq + (size_t)image * c->feat_cap * 128, sizeof(double) * 128 * (size_t)nf,
+                                 hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SG_OK;
+}
+
+// ---- timing ---------------------------------------------------------------------------------------------------
+
+int sg_set_profiling(sg_ctx *c, int on)
+{
+    if (!c)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    if (on && !c->ev.created) {
+        for (int i = 0; i < kEventPairs; i++) {
+            HIPCHK(c, hipEventCreate(&c->ev.start[i]));
+            HIPCHK(c, hipEventCreate(&c->ev.stop[i]));
+        }
+        c->ev.created = true;
+    }
+    if (!on)
+        flush_events(c);
+    c->prof = on != 0;
+    return SG_OK;
+}
+
+int sg_get_stage_times(sg_ctx *c, double *ms, unsigned long long *launches)
+{
+    if (!c)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    flush_events(c);
+    for (int i = 0; i < SG_ST_COUNT; i++) {
+        if (ms)
+            ms[i] = c->stage_ms[i];
+        if (launches)
+            launches[i] = c->stage_launches[i];
+    }
+    return SG_OK;
+}
+
+int sg_reset_stage_times(sg_ctx *c)
+{
+    if (!c)
+        return SG_E_INVALID;
+    flush_events(c);
+    memset(c->stage_ms, 0, sizeof c->stage_ms);
+    memset(c->stage_launches, 0, sizeof c->stage_launches);
+    return SG_OK;
+}
+
+// ---- device memory, synthetic input -----------------------------------------------------------------------------
+
+int sg_malloc(sg_ctx *c, size_t bytes, void **d_ptr)
+{
+    if (!c || !d_ptr)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    HIPCHK(c, hipMalloc(d_ptr, bytes));
+    return SG_OK;
+}
+
+int sg_free(sg_ctx *c, void *d_ptr)
+{
+    if (!c)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipFree(d_ptr));
+    return SG_OK;
+}
+
+int sg_memcpy_h2d(sg_ctx *c, void *d_dst, const void *src, size_t bytes)
+{
+    if (!c)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    HIPCHK(c, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SG_OK;
+}
+
+int sg_memcpy_d2h(sg_ctx *c, void *dst, const void *d_src, size_t bytes)
+{
+    if (!c)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SG_OK;
+}
+
+int sg_synth_vnoise5(sg_ctx *c, uint8_t *d_dst, int width, int height, uint64_t seed)
+{
+    if (!c || !d_dst || width < 1 || height < 1)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    launch_vnoise5(d_dst, height, width, seed, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return SG_OK;
+}
+
+} // extern "C"
+
+// ===================================================================== stage entry points (host pointers)
+//
+// Each uploads its operands into temporary device planes, runs the same kernels the whole path uses
+// (batch of one) and downloads the result.  They exist for drop-in use of the reference's stage-level
+// functions and for parity tests of single stages; they allocate and synchronise freely.
+
+namespace {
+
+struct TmpPlane {
+    Plane pl;
+    sg_ctx *c;
+    TmpPlane(sg_ctx *ctx, int rows, int cols) : c(ctx)
+    {
+        pl.rows = rows;
+        pl.cols = cols;
+        pl.pitch = pitch_of(cols);
+        pl.img_stride = (size_t)rows * pl.pitch;
+        if (hipMalloc(&pl.p, c->esize * (pl.img_stride + 64)) != hipSuccess)
+            pl.p = nullptr;
+    }
+    ~TmpPlane()
+    {
+        if (pl.p)
+            (void)hipFree(pl.p);
+    }
+    bool ok() const { return pl.p != nullptr; }
+    int upload(const double *src)
+    {
+        std::vector<unsigned char> host(c->esize * pl.img_stride, 0);
+        for (int y = 0; y < pl.rows; y++)
+            for (int x = 0; x < pl.cols; x++) {
+                double v = src[(size_t)y * pl.cols + x];
+                if (c->esize == 8)
+                    ((double *)host.data())[(size_t)y * pl.pitch + x] = v;
+                else
+                    ((float *)host.data())[(size_t)y * pl.pitch + x] = (float)v;
+            }
+        HIPCHK(c, hipMemcpyAsync(pl.p, host.data(), host.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return SG_OK;
+    }
+    int download(double *dst) { return download_plane(c, pl, 0, dst); }
+};
+
+int finish(sg_ctx *c)
+{
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SG_OK;
+}
+
+int blur_tmp(sg_ctx *c, const Plane &src, const Plane &dst, double sigma)
+{
+    std::vector<double> taps(1024);
+    int n = gaussian_taps(sigma, taps.data(), 1024);
+    if (n < 0)
+        return fail(c, SG_E_UNSUPPORTED, "sigma too large");
+    TmpPlane tmp(c, src.rows, src.cols);
+    if (!tmp.ok())
+        return fail(c, SG_E_NOMEM, "out of device memory");
+    launch_blur_row(src, tmp.pl, 1, taps.data(), n, c->prm.precision, c->stream);
+    launch_blur_col(tmp.pl, dst, 1, taps.data(), n, c->prm.precision, c->stream);
+    return finish(c);
+}
+
+// uploads a pyramid of `per_octave` levels per octave and fills an OctaveTab over it
+struct TmpPyramid {
+    std::vector<TmpPlane *> planes;
+    OctaveTab tab;
+    unsigned int n_words = 0;
+    ~TmpPyramid()
+    {
+        for (TmpPlane *p : planes)
+            delete p;
+    }
+    int build(sg_ctx *c, const double *const *levels, int width, int height, int octaves, int per_octave, bool from_dog)
+    {
+        Geometry g;
+        int rc = make_geometry(height, width, octaves, &g);
+        if (rc != SG_OK)
+            return fail(c, rc, "too many octaves");
+        memset(&tab, 0, sizeof tab);
+        for (int o = 0; o < octaves; o++) {
+            for (int l = 0; l < per_octave; l++) {
+                TmpPlane *p = new TmpPlane(c, g.rows[o], g.cols[o]);
+                planes.push_back(p);
+                if (!p->ok())
+                    return fail(c, SG_E_NOMEM, "out of device memory");
+                rc = p->upload(levels[o * per_octave + l]);
+                if (rc != SG_OK)
+                    return rc;
+                tab.lv[o][l] = p->pl.p;
+            }
+            tab.rows[o] = g.rows[o];
+            tab.cols[o] = g.cols[o];
+            tab.pitch[o] = g.pitch[o];
+            tab.img_stride[o] = 0;
+            tab.nrows[o] = g.nrows[o];
+            tab.wpr[o] = g.wpr[o];
+        }
+        for (int o = 0; o <= kMaxOctaves; o++)
+            tab.wbase[o] = g.wbase[o];
+        tab.octaves = octaves;
+        tab.from_dog = from_dog ? 1 : 0;
+        n_words = g.wbase[octaves];
+        return SG_OK;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+int sg_convert_to_gray(sg_ctx *c, const uint8_t *px, int width, int height, int channels, size_t stride, double *dst)
+{
+    if (!c || !px || !dst || width < 1 || height < 1 || channels < 3)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    int rc = ensure_in(c, stride * (size_t)height);
+    if (rc != SG_OK)
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, px, stride * (size_t)height, hipMemcpyHostToDevice, c->stream));
+    TmpPlane out(c, height, width);
+    if (!out.ok())
+        return fail(c, SG_E_NOMEM, "out of device memory");
+    launch_gray(c->d_in, height, width, channels, stride, 0, out.pl, 1, c->prm.precision, c->stream);
+    rc = finish(c);
+    return rc != SG_OK ? rc : out.download(dst);
+}
+
+int sg_upsample(sg_ctx *c, const double *src, int width, int height, double *dst)
+{
+    if (!c || !src || !dst || width < 2 || height < 2)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    TmpPlane in(c, height, width), out(c, 2 * height, 2 * width);
+    if (!in.ok() || !out.ok())
+        return fail(c, SG_E_NOMEM, "out of device memory");
+    int rc = in.upload(src);
+    if (rc != SG_OK)
+        return rc;
+    launch_upsample(in.pl, out.pl, 1, c->prm.precision, c->stream);
+    rc = finish(c);
+    return rc != SG_OK ? rc : out.download(dst);
+}
+
+int sg_downsample(sg_ctx *c, const double *src, int width, int height, double *dst)
+{
+    if (!c || !src || !dst || width < 1 || height < 1)
+        return SG_E_INVALID;
+    if (width <= 1 || height <= 1) { // DownSample copies such a source (sift.cpp:64-68)
+        memcpy(dst, src, sizeof(double) * (size_t)width * height);
+        return SG_OK;
+    }
+    (void)hipSetDevice(c->prm.device);
+    TmpPlane in(c, height, width), out(c, height / 2, width / 2);
+    if (!in.ok() || !out.ok())
+        return fail(c, SG_E_NOMEM, "out of device memory");
+    int rc = in.upload(src);
+    if (rc != SG_OK)
+        return rc;
+    launch_downsample(in.pl, out.pl, 1, c->prm.precision, c->stream);
+    rc = finish(c);
+    return rc != SG_OK ? rc : out.download(dst);
+}
+
+int sg_gaussian_smooth(sg_ctx *c, const double *src, double *dst, int width, int height, double sigma)
+{
+    if (!c || !src || !dst || width < 1 || height < 1 || !(sigma > 0))
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    TmpPlane in(c, height, width), out(c, height, width);
+    if (!in.ok() || !out.ok())
+        return fail(c, SG_E_NOMEM, "out of device memory");
+    int rc = in.upload(src);
+    if (rc != SG_OK)
+        return rc;
+    rc = blur_tmp(c, in.pl, out.pl, sigma);
+    return rc != SG_OK ? rc : out.download(dst);
+}
+
+int sg_create_init_smooth_gray(sg_ctx *c, const uint8_t *px, int width, int height, int channels, size_t stride,
+                               double sigma, double *dst)
+{
+    if (!c || !px || !dst || width < 2 || height < 2 || channels < 3 || !(sigma > 1.0))
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    int rc = ensure_in(c, stride * (size_t)height);
+    if (rc != SG_OK)
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, px, stride * (size_t)height, hipMemcpyHostToDevice, c->stream));
+    TmpPlane up(c, 2 * height, 2 * width), out(c, 2 * height, 2 * width);
+    if (!up.ok() || !out.ok())
+        return fail(c, SG_E_NOMEM, "out of device memory");
+    launch_gray_upsample(c->d_in, height, width, channels, stride, 0, up.pl, 1, c->prm.precision, c->stream);
+    double sigma_init = sqrt(sigma * sigma - (0.5 * 2) * (0.5 * 2));
+    rc = blur_tmp(c, up.pl, out.pl, sigma_init);
+    return rc != SG_OK ? rc : out.download(dst);
+}
+
+int sg_gaussian_pyramid(sg_ctx *c, const double *base, int width, int height, int octaves, int intervals, double sigma,
+                        double *const *levels)
+{
+    if (!c || !base || !levels || width < 1 || height < 1 || octaves < 0)
+        return SG_E_INVALID;
+    if (intervals != 3)
+        return SG_E_UNSUPPORTED;
+    (void)hipSetDevice(c->prm.device);
+    Geometry g;
+    int rc = make_geometry(height, width, octaves, &g);
+    if (rc != SG_OK)
+        return rc;
+    double sig[kLevels];
+    double k = pow(2.0, 1.0 / intervals);
+    sig[0] = sigma;
+    for (int i = 1; i < kLevels; i++) {
+        double sig_prev = pow(k, i - 1) * sigma;
+        double sig_total = sig_prev * k;
+        sig[i] = sqrt(sig_total * sig_total - sig_prev * sig_prev);
+    }
+    TmpPlane *prev3 = nullptr;
+    std::vector<TmpPlane *> keep;
+    auto cleanup = [&]() {
+        for (TmpPlane *p : keep)
+            delete p;
+    };
+    for (int o = 0; o < octaves; o++) {
+        TmpPlane *lv[kLevels];
+        for (int l = 0; l < kLevels; l++) {
+            lv[l] = new TmpPlane(c, g.rows[o], g.cols[o]);
+            keep.push_back(lv[l]);
+            if (!lv[l]->ok()) {
+                cleanup();
+                return fail(c, SG_E_NOMEM, "out of device memory");
+            }
+        }
+        if (o == 0)
+            rc = lv[0]->upload(base);
+        else if (g.rows[o] == g.rows[o - 1]) {
+            rc = hipMemcpy(lv[0]->pl.p, prev3->pl.p, c->esize * lv[0]->pl.img_stride, hipMemcpyDeviceToDevice) == hipSuccess
+                     ? SG_OK : SG_E_HIP;
+        } else {
+            launch_downsample(prev3->pl, lv[0]->pl, 1, c->prm.precision, c->stream);
+            rc = finish(c);
+        }
+        for (int l = 1; l < kLevels && rc == SG_OK; l++)
+            rc = blur_tmp(c, lv[l - 1]->pl, lv[l]->pl, sig[l]);
+        for (int l = 0; l < kLevels && rc == SG_OK; l++)
+            rc = lv[l]->download(levels[o * kLevels + l]);
+        if (rc != SG_OK) {
+            cleanup();
+            return rc;
+        }
+        prev3 = lv[3];
+    }
+    cleanup();
+    return SG_OK;
+}
+
+int sg_sub(sg_ctx *c, const double *a, const double *b, double *out, int width, int height)
+{
+    if (!c || !a || !b || !out || width < 1 || height < 1)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    TmpPlane pa(c, height, width), pb(c, height, width), pc(c, height, width);
+    if (!pa.ok() || !pb.ok() || !pc.ok())
+        return fail(c, SG_E_NOMEM, "out of device memory");
+    int rc = pa.upload(a);
+    if (rc == SG_OK)
+        rc = pb.upload(b);
+    if (rc != SG_OK)
+        return rc;
+    launch_sub(pa.pl, pb.pl, pc.pl, 1, c->prm.precision, c->stream);
+    rc = finish(c);
+    return rc != SG_OK ? rc : pc.download(out);
+}
+
+int sg_dog_pyramid(sg_ctx *c, const double *const *gauss, int width, int height, int octaves, int intervals,
+                   double *const *dog)
+{
+    if (!c || !gauss || !dog || octaves < 0)
+        return SG_E_INVALID;
+    if (intervals != 3)
+        return SG_E_UNSUPPORTED;
+    Geometry g;
+    int rc = make_geometry(height, width, octaves, &g);
+    if (rc != SG_OK)
+        return rc;
+    for (int o = 0; o < octaves; o++)
+        for (int i = 1; i < kLevels; i++) {
+            rc = sg_sub(c, gauss[o * kLevels + i], gauss[o * kLevels + i - 1], dog[o * kDogLevels + i - 1], g.cols[o],
+                        g.rows[o]);
+            if (rc != SG_OK)
+                return rc;
+        }
+    return SG_OK;
+}
+
+int sg_detect_local_extrema(sg_ctx *c, const double *const *dog, int width, int height, int octaves, int intervals,
+                            int nointerval, sg_keypoint *out, size_t cap, size_t *n, sg_counters *counters)
+{
+    if (!c || !dog || !n || octaves < 0 || (cap && !out))
+        return SG_E_INVALID;
+    if (intervals != 3)
+        return SG_E_UNSUPPORTED;
+    (void)hipSetDevice(c->prm.device);
+    TmpPyramid pyr;
+    int rc = pyr.build(c, dog, width, height, octaves, kDogLevels, true);
+    if (rc != SG_OK)
+        return rc;
+    if (pyr.n_words > c->words_img)
+        return fail(c, SG_E_CAPACITY, "pyramid larger than the context was sized for");
+    (void)hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int) * 4, c->stream);
+    detect_phase(c, pyr.tab, pyr.n_words, 1, nointerval);
+    rc = check_overflow(c);
+    if (rc != SG_OK)
+        return rc;
+    std::vector<KpRec> recs;
+    rc = download_keypoints(c, 0, &recs);
+    if (rc != SG_OK)
+        return rc;
+    if (counters)
+        sg_read_counters(c, 0, counters);
+    *n = recs.size();
+    if (recs.size() > cap)
+        return SG_E_CAPACITY;
+    for (size_t i = 0; i < recs.size(); i++) {
+        kprec_to_keypoint(recs[i], &out[i]);
+        // the reference's detector leaves scale fields unset and keeps base-image coordinates (sift.cpp:895-907)
+        out[i].dx = (out[i].x + out[i].offset_x) * pow(2.0, out[i].octave);
+        out[i].dy = (out[i].y + out[i].offset_y) * pow(2.0, out[i].octave);
+        out[i].scale = 0;
+        out[i].octave_scale = 0;
+    }
+    return SG_OK;
+}
+
+int sg_calculate_scale(sg_keypoint *kp, size_t n, double sigma, int intervals)
+{
+    if (!kp && n)
+        return SG_E_INVALID;
+    for (size_t i = 0; i < n; i++) {
+        double intvl = kp[i].interval + kp[i].offset_interval;
+        kp[i].scale = sigma * pow(2.0, kp[i].octave + intvl / intervals);
+        kp[i].octave_scale = sigma * pow(2.0, intvl / intervals);
+    }
+    return SG_OK;
+}
+
+int sg_half_features(sg_keypoint *kp, size_t n)
+{
+    if (!kp && n)
+        return SG_E_INVALID;
+    for (size_t i = 0; i < n; i++) {
+        kp[i].dx /= 2;
+        kp[i].dy /= 2;
+        kp[i].scale /= 2;
+    }
+    return SG_OK;
+}
+
+static int upload_records(sg_ctx *c, const sg_keypoint *recs, size_t n, bool with_ori)
+{
+    if (n > c->feat_cap)
+        return fail(c, SG_E_CAPACITY, "more records than the context's feature capacity");
+    std::vector<KpRec> kp(n);
+    std::vector<unsigned int> ident(n), fsrc(n);
+    std::vector<double> ori(with_ori ? n * kOriBins : 0);
+    for (size_t i = 0; i < n; i++) {
+        keypoint_to_kprec(recs[i], &kp[i]);
+        ident[i] = (unsigned int)i;
+        fsrc[i] = (unsigned int)i * 64u;
+        if (with_ori)
+            ori[i * kOriBins] = recs[i].ori;
+    }
+    unsigned int cnt = (unsigned int)n;
+    hipStream_t s = c->stream;
+    if (n) {
+        HIPCHK(c, hipMemcpyAsync(c->d_kp, kp.data(), sizeof(KpRec) * n, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->d_kpsrc, ident.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, s));
+        if (with_ori) {
+            HIPCHK(c, hipMemcpyAsync(c->d_fsrc, fsrc.data(), sizeof(unsigned int) * n, hipMemcpyHostToDevice, s));
+            HIPCHK(c, hipMemcpyAsync(c->d_ori, ori.data(), sizeof(double) * ori.size(), hipMemcpyHostToDevice, s));
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_counts + c->B, &cnt, sizeof cnt, hipMemcpyHostToDevice, s));
+    if (with_ori)
+        HIPCHK(c, hipMemcpyAsync(c->d_counts + 2 * c->B, &cnt, sizeof cnt, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    return SG_OK;
+}
+
+int sg_orientation_assignment(sg_ctx *c, const sg_keypoint *extrema, size_t n_extrema, const double *const *gauss,
+                              int width, int height, int octaves, sg_keypoint *out, size_t cap, size_t *n)
+{
+    if (!c || !gauss || !n || (n_extrema && !extrema) || (cap && !out))
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    TmpPyramid pyr;
+    int rc = pyr.build(c, gauss, width, height, octaves, kLevels, false);
+    if (rc != SG_OK)
+        return rc;
+    rc = upload_records(c, extrema, n_extrema, false);
+    if (rc != SG_OK)
+        return rc;
+    (void)hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int) * 4, c->stream);
+    (void)hipMemsetAsync(c->d_chunks + c->chunks1 + c->chunks2, 0, sizeof(unsigned int) * c->chunks3, c->stream);
+    orient_phase(c, pyr.tab, 1);
+    rc = check_overflow(c);
+    if (rc != SG_OK)
+        return rc;
+    unsigned int nf = 0;
+    HIPCHK(c, hipMemcpy(&nf, c->d_counts + 2 * c->B, sizeof nf, hipMemcpyDeviceToHost));
+    *n = nf;
+    if (nf > cap)
+        return SG_E_CAPACITY;
+    if (!nf)
+        return SG_OK;
+    std::vector<unsigned int> fsrc(nf);
+    std::vector<double> ori((size_t)n_extrema * kOriBins);
+    HIPCHK(c, hipMemcpy(fsrc.data(), c->d_fsrc, sizeof(unsigned int) * nf, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(ori.data(), c->d_ori, sizeof(double) * ori.size(), hipMemcpyDeviceToHost));
+    for (unsigned int f = 0; f < nf; f++) {
+        unsigned int j = fsrc[f] >> 6, bin = fsrc[f] & 63;
+        out[f] = extrema[j]; // CopyKeypoint (sift.cpp:1249-1267); descriptor fields are not meaningful yet
+        out[f].descr_length = 0;
+        memset(out[f].descriptor, 0, sizeof out[f].descriptor);
+        out[f].ori = ori[(size_t)j * kOriBins + bin];
+    }
+    return SG_OK;
+}
+
+int sg_descriptor_representation(sg_ctx *c, sg_keypoint *features, size_t n, const double *const *gauss, int width,
+                                 int height, int octaves)
+{
+    if (!c || !gauss || (n && !features))
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    TmpPyramid pyr;
+    int rc = pyr.build(c, gauss, width, height, octaves, kLevels, false);
+    if (rc != SG_OK)
+        return rc;
+    rc = upload_records(c, features, n, true);
+    if (rc != SG_OK)
+        return rc;
+    descr_phase(c, pyr.tab, 1);
+    rc = finish(c);
+    if (rc != SG_OK || !n)
+        return rc;
+    std::vector<uint8_t> desc(n * 128);
+    HIPCHK(c, hipMemcpy(desc.data(), c->d_desc, desc.size(), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) {
+        features[i].descr_length = 128;
+        for (int k = 0; k < 128; k++)
+            features[i].descriptor[k] = desc[i * 128 + k];
+    }
+    return SG_OK;
+}
+
+int sg_sort_features(sg_ctx *c, sg_keypoint *features, size_t n)
+{
+    if (!c || (n && !features))
+        return SG_E_INVALID;
+    if (n > c->feat_cap)
+        return fail(c, SG_E_CAPACITY, "more records than the context's feature capacity");
+    if (n < 2)
+        return SG_OK;
+    (void)hipSetDevice(c->prm.device);
+    std::vector<double> sc(n);
+    for (size_t i = 0; i < n; i++)
+        sc[i] = features[i].scale;
+    unsigned int cnt = (unsigned int)n;
+    HIPCHK(c, hipMemcpyAsync(c->d_fscale, sc.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_counts + 2 * c->B, &cnt, sizeof cnt, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    rank_phase(c, 1);
+    int rc = finish(c);
+    if (rc != SG_OK)
+        return rc;
+    std::vector<unsigned int> rank(n);
+    HIPCHK(c, hipMemcpy(rank.data(), c->d_rank, sizeof(unsigned int) * n, hipMemcpyDeviceToHost));
+    std::vector<sg_keypoint> tmp(features, features + n);
+    for (size_t i = 0; i < n; i++)
+        features[rank[i]] = tmp[i];
+    return SG_OK;
+}
+
+} // extern "C"

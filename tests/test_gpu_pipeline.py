@@ -1,0 +1,189 @@
+"""Parity of the whole path through the C ABI against the CPU oracle on the same seeded inputs."""
+import numpy as np
+import pytest
+
+from sift_amd.parity import descriptor_agreement, match_features
+
+pytestmark = pytest.mark.gpu
+
+FIELDS_EXACT = ("octave", "interval", "x", "y")
+FIELDS_F64 = ("offset_interval", "offset_x", "offset_y", "dx", "dy", "val")
+
+
+@pytest.fixture(scope="module", params=[(96, 64, 1), (200, 150, 1234), (320, 240, 7)])
+def case(request, oracle, gpu64):
+    w, h, seed = request.param
+    img = oracle.vnoise5(w, h, seed)
+    dbg = oracle.Debug(img, prequant=True)
+    feats = gpu64.extract(img)
+    return dict(img=img, dbg=dbg, feats=feats, ctx=gpu64)
+
+
+def test_pyramid_levels_bitexact(case):
+    dbg, ctx = case["dbg"], case["ctx"]
+    assert ctx.last_octaves() == dbg.octaves
+    for o in range(dbg.octaves):
+        for l in range(6):
+            got = ctx.read_level(o, l)
+            assert np.array_equal(got, dbg.gauss[o * 6 + l]), "octave %d level %d" % (o, l)
+
+
+def test_counters_and_keypoints(case):
+    dbg, ctx = case["dbg"], case["ctx"]
+    assert ctx.read_counters() == dbg.counters
+    kps = ctx.read_keypoints()
+    ref = dbg.keypoints
+    assert len(kps) == len(ref)
+    for f in FIELDS_EXACT:
+        assert np.array_equal(kps[f], ref[f]), f
+    for f in FIELDS_F64:  # same operation order in double, no contraction: identical bits
+        assert np.array_equal(kps[f], ref[f]), f
+    # pow() comes from different math libraries: allow an ulp
+    assert np.allclose(kps["scale"], ref["scale"], rtol=1e-14, atol=0)
+    assert np.allclose(kps["octave_scale"], ref["octave_scale"], rtol=1e-14, atol=0)
+
+
+def test_features_unsorted(case):
+    dbg, ctx = case["dbg"], case["ctx"]
+    got, pq = ctx.read_features_unsorted(prequant=True)
+    ref = dbg.features
+    assert len(got) == len(ref)
+    for f in FIELDS_EXACT:
+        assert np.array_equal(got[f], ref[f]), f
+    d = np.abs(got["ori"] - ref["ori"])
+    d = np.minimum(d, 2 * np.pi - d)
+    assert d.max() < 1e-9
+    # float descriptor before quantisation: L2 distance after normalisation
+    l2 = np.linalg.norm(pq - dbg.prequant, axis=1)
+    assert l2.max() < 1e-9
+    # integer bins identical
+    assert np.array_equal(got["descriptor"], ref["descriptor"])
+    assert (got["descr_length"] == 128).all()
+
+
+def test_sorted_output_order(case):
+    dbg, feats = case["dbg"], case["feats"]
+    ref = dbg.sorted_features
+    assert len(feats) == len(ref)
+    assert (np.diff(feats["scale"]) >= 0).all()
+    for f in FIELDS_EXACT:
+        assert np.array_equal(feats[f], ref[f]), f
+    assert np.array_equal(feats["descriptor"], ref["descriptor"])
+
+
+def test_north_star_tolerances(case):
+    dbg, feats = case["dbg"], case["feats"]
+    ref = dbg.sorted_features
+    pairs = match_features(ref, feats, pos_tol=0.5, scale_tol=0.01, ori_tol_deg=1.0)
+    assert len(pairs) >= 0.99 * len(ref)
+    same_desc, same_bins, l2 = descriptor_agreement(ref["descriptor"][pairs[:, 0]], feats["descriptor"][pairs[:, 1]])
+    assert same_desc >= 0.99 and l2 < 1e-3
+
+
+def test_determinism(case):
+    ctx, img = case["ctx"], case["img"]
+    a = ctx.extract(img)
+    b = ctx.extract(img)
+    assert a.tobytes() == b.tobytes()
+    assert a.tobytes() == case["feats"].tobytes()
+
+
+def test_float_pyramid_meets_tolerances(oracle, gpu32):
+    img = oracle.vnoise5(320, 240, 7)
+    ref, _, _, _ = oracle.sift(img)
+    got = gpu32.extract(img)
+    pairs = match_features(ref, got)
+    assert len(pairs) >= 0.99 * len(ref)
+    assert len(got) <= 1.01 * len(ref) + 2
+    same_desc, same_bins, l2 = descriptor_agreement(ref["descriptor"][pairs[:, 0]], got["descriptor"][pairs[:, 1]])
+    # a float pyramid flips a few (int)(512 v) truncations by one: bins agree to 99.9 %, descriptors to > 95 %
+    assert same_bins >= 0.999
+    assert same_desc >= 0.95
+
+
+def test_nointerval_variant(oracle):
+    import sift_amd
+    img = oracle.vnoise5(200, 150, 21)
+    ref, nk, ctr, _ = oracle.sift(img, nointerval=True)
+    with sift_amd.SiftGPU(max_width=200, max_height=150, nointerval=True) as ctx:
+        got = ctx.extract(img)
+        assert ctx.read_counters() == ctr
+    assert len(got) == len(ref)
+    assert np.array_equal(got["descriptor"], ref["descriptor"])
+    assert np.array_equal(got["x"], ref["x"]) and np.array_equal(got["y"], ref["y"])
+
+
+def test_batch_device_matches_single(oracle, gpu64):
+    import sift_amd
+    w, h, n = 160, 120, 3
+    imgs = np.stack([oracle.vnoise5(w, h, 100 + i) for i in range(n)])
+    singles = [gpu64.extract(imgs[i]) for i in range(n)]
+    cap = 4096
+    packed = gpu64.extract_batch(imgs, cap)
+    for i in range(n):
+        s = singles[i]
+        p = packed[i]
+        assert len(p) == len(s)
+        assert np.array_equal(p["desc"], s["descriptor"].astype(np.uint8))
+        assert np.allclose(p["x"], s["dx"], atol=1e-3) and np.allclose(p["scale"], s["scale"], rtol=1e-6)
+    # device-pointer form with on-device synthetic input
+    d_img = gpu64.malloc(n * w * h * 3)
+    d_out = gpu64.malloc(n * cap * 144)
+    d_cnt = gpu64.malloc(n * 4)
+    try:
+        for i in range(n):
+            gpu64.synth_vnoise5(d_img + i * w * h * 3, w, h, 100 + i)
+        gpu64.extract_batch_device(d_img, n, w, h, 3, d_out, cap, d_cnt)
+        gpu64.sync()
+        cnt = np.zeros(n, dtype=np.uint32)
+        gpu64.d2h(cnt, d_cnt)
+        out = np.zeros((n, cap), dtype=sift_amd.PACKED_DTYPE)
+        gpu64.d2h(out, d_out)
+    finally:
+        gpu64.free(d_img)
+        gpu64.free(d_out)
+        gpu64.free(d_cnt)
+    for i in range(n):
+        assert cnt[i] == len(singles[i])
+        assert out[i, : cnt[i]].tobytes() == packed[i].tobytes()
+
+
+def test_flat_image_has_no_features(gpu64):
+    img = np.full((64, 64, 3), 128, dtype=np.uint8)
+    assert len(gpu64.extract(img)) == 0
+    assert gpu64.read_counters()[1:] == (0, 0, 0, 0)
+
+
+def test_capacity_overflow_is_reported(oracle):
+    import sift_amd
+    img = oracle.vnoise5(200, 150, 5)
+    with sift_amd.SiftGPU(max_width=200, max_height=150, max_features=16) as ctx:
+        with pytest.raises(sift_amd.SiftGpuError) as e:
+            ctx.extract(img)
+        assert e.value.status == sift_amd.api.SG_E_CAPACITY
+
+
+def test_stage_entry_points_chain(oracle, gpu64):
+    """GaussianPyramid -> DogPyramid -> DetectionLocalExtrema -> CalculateScale/HalfFeatures ->
+    OrientationAssignment -> DescriptorRepresentation -> sort, each through its own entry point."""
+    img = oracle.vnoise5(160, 120, 77)
+    dbg = oracle.Debug(img)
+    base = gpu64.create_init_smooth_gray(img, 1.6)
+    octaves = oracle.num_octaves(*base.shape)
+    gauss = gpu64.gaussian_pyramid(base, octaves)
+    for a, b in zip(gauss, dbg.gauss):
+        assert np.array_equal(a, b)
+    dog = gpu64.dog_pyramid(gauss, octaves)
+    for a, b in zip(dog, dbg.dog):
+        assert np.array_equal(a, b)
+    ext, ctr = gpu64.detect_local_extrema(dog, octaves)
+    assert ctr == dbg.counters
+    ext = gpu64.half_features(gpu64.calculate_scale(ext))
+    for f in ("x", "y", "octave", "interval", "dx", "dy", "scale", "octave_scale", "val"):
+        assert np.array_equal(ext[f], dbg.keypoints[f]), f
+    feats = gpu64.orientation_assignment(ext, gauss, octaves)
+    assert len(feats) == len(dbg.features)
+    feats = gpu64.descriptor_representation(feats, gauss, octaves)
+    assert np.array_equal(feats["descriptor"], dbg.features["descriptor"])
+    srt = gpu64.sort_features(feats)
+    assert np.array_equal(srt["descriptor"], dbg.sorted_features["descriptor"])

@@ -175,16 +175,16 @@ int sg_read_features_unsorted(sg_ctx *ctx, int image, sg_keypoint *out, size_t c
 /* ---- timing: HIP events recorded on the context's stream around each stage ------------------- */
 
 typedef enum sg_stage {
-    SG_ST_PREP = 0,   /* gray + upsample */
-    SG_ST_BLUR_ROW,   /* all row-pass launches */
-    SG_ST_BLUR_COL,   /* all column-pass launches */
-    SG_ST_DOWNSAMPLE,
-    SG_ST_DETECT,     /* fused DoG + extrema scan */
-    SG_ST_COMPACT,    /* ordered compaction launches */
+    SG_ST_PREP = 0,       /* gray + upsample */
+    SG_ST_BLUR_ROW0 = 1,  /* row-pass launches; +0 initial blur, +1..+5 pyramid levels 1..5 */
+    SG_ST_BLUR_COL0 = 7,  /* column-pass launches, same sub-index */
+    SG_ST_DOWNSAMPLE = 13,
+    SG_ST_DETECT,         /* fused DoG + extrema scan */
+    SG_ST_COMPACT,        /* ordered compaction launches */
     SG_ST_REFINE,
     SG_ST_ORIENT,
     SG_ST_DESCR,
-    SG_ST_SORT,       /* rank + output packing */
+    SG_ST_SORT,           /* rank + output packing */
     SG_ST_COUNT
 } sg_stage;
 

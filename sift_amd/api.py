@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libsiftgpu.so")
 
 SG_OK, SG_E_INVALID, SG_E_HIP, SG_E_CAPACITY, SG_E_UNSUPPORTED, SG_E_NOMEM = 0, -1, -2, -3, -4, -5
 SG_F64, SG_F32 = 0, 1
-STAGES = ("prep", "blur_row", "blur_col", "downsample", "detect", "compact", "refine", "orient", "descr", "sort")
+STAGES = (("prep",) + tuple("blur_row%d" % i for i in range(6)) + tuple("blur_col%d" % i for i in range(6)) +
+          ("downsample", "detect", "compact", "refine", "orient", "descr", "sort"))
 
 # Mirror of the reference's struct Keypoint (sift/sift.h:75-102), 1120 bytes.
 KEYPOINT_DTYPE = np.dtype({

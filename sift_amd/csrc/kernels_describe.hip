@@ -373,7 +373,8 @@ __global__ __launch_bounds__(256) void pack_k(const KpRec *kp, size_t kp_img, co
                 o->octave = r.octave; o->interval = r.interval; o->offset_interval = r.offi;
                 o->x = r.x; o->y = r.y; o->scale = r.scale; o->dx = r.dx; o->dy = r.dy;
                 o->offset_x = r.offx; o->offset_y = r.offy; o->octave_scale = r.oscale; o->ori = ori;
-                o->descr_length = 128; o->val = r.val;
+                // descr_length and the 4 padding bytes behind it in one store, so that records are byte-reproducible
+                *reinterpret_cast<unsigned long long *>(&o->descr_length) = 128ull; o->val = r.val;
             }
         }
     }

@@ -24,7 +24,7 @@ static_assert(sizeof(KpRec) == 80, "KpRec is 80 bytes");
 
 namespace {
 
-constexpr int kEventPairs = 1024;
+constexpr int kEventPairs = 4096;
 
 struct StageEvents {
     hipEvent_t start[kEventPairs], stop[kEventPairs];
@@ -357,18 +357,18 @@ static void pack_phase(sg_ctx *c, void *out, size_t out_img_stride, unsigned int
 }
 
 // blur src -> dst through the context's row-pass scratch plane
-static void blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, const double *taps, int n)
+static void blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, const double *taps, int n, int slot)
 {
     Plane tmp = src;
     tmp.p = c->d_tmp;
     tmp.pitch = src.pitch;
     tmp.img_stride = (size_t)src.rows * src.pitch;
     {
-        StageScope sc(c, SG_ST_BLUR_ROW);
+        StageScope sc(c, SG_ST_BLUR_ROW0 + slot);
         launch_blur_row(src, tmp, B, taps, n, c->prm.precision, c->stream);
     }
     {
-        StageScope sc(c, SG_ST_BLUR_COL);
+        StageScope sc(c, SG_ST_BLUR_COL0 + slot);
         launch_blur_col(tmp, dst, B, taps, n, c->prm.precision, c->stream);
     }
 }
@@ -398,7 +398,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
         StageScope sc(c, SG_ST_PREP);
         launch_gray_upsample(d_imgs, h, w, ch, stride, img_stride, up, B, prec, s);
     }
-    blur_planes(c, up, c->level[0][0], B, c->taps[0], c->ntaps[0]);
+    blur_planes(c, up, c->level[0][0], B, c->taps[0], c->ntaps[0], 0);
     for (int o = 0; o < c->octaves; o++) {
         if (o > 0) {
             StageScope sc(c, SG_ST_DOWNSAMPLE);
@@ -409,7 +409,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
                 launch_downsample(c->level[o - 1][3], c->level[o][0], B, prec, s);
         }
         for (int l = 1; l < kLevels; l++)
-            blur_planes(c, c->level[o][l - 1], c->level[o][l], B, c->taps[l], c->ntaps[l]);
+            blur_planes(c, c->level[o][l - 1], c->level[o][l], B, c->taps[l], c->ntaps[l], l);
     }
     detect_phase(c, c->tab, c->n_words, B, c->prm.nointerval);
     orient_phase(c, c->tab, B);

@@ -84,8 +84,10 @@ def test_determinism(case):
     ctx, img = case["ctx"], case["img"]
     a = ctx.extract(img)
     b = ctx.extract(img)
-    assert a.tobytes() == b.tobytes()
-    assert a.tobytes() == case["feats"].tobytes()
+    # field by field (numpy does not carry a record's padding bytes through a copy)
+    for f in a.dtype.names:
+        assert a[f].tobytes() == b[f].tobytes(), f
+        assert a[f].tobytes() == case["feats"][f].tobytes(), f
 
 
 def test_float_pyramid_meets_tolerances(oracle, gpu32):

@@ -1,6 +1,7 @@
 // kernels_describe.hip -- orientation assignment, 4x4x8 descriptors, scale ordering and output packing
 // for gfx950.  All histogram arithmetic is double precision whatever the pyramid's storage type.
 #include "sg_internal.h"
+#include "sg_math.h"
 
 namespace sg {
 
@@ -19,14 +20,21 @@ __device__ __forceinline__ bool grad_at(const T *g, int rows, int cols, int pitc
     return false;
 }
 
+__device__ __forceinline__ void lds_add(double *p, double v)
+{
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ---- orientation ---------------------------------------------------------------------------------------
-// One wave per keypoint.  CalculateOrientationHistogram (sift.cpp:1149-1199): every lane accumulates its
-// samples into a lane-private 36-bin column of an LDS table (no atomics), lane b then adds the 64 partial
-// sums of bin b in lane order, so the histogram is reproducible run to run.  Two passes of the circular
+// One wave per keypoint.  CalculateOrientationHistogram (sift.cpp:1149-1199): the lanes walk the
+// (2r+1)^2 window and add mag*weight into wave-private 36-bin LDS histograms with double atomics.  Each
+// wave keeps four copies (lane & 3) so that neighbouring lanes, whose gradients point the same way, do
+// not serialise on one bin; copies are added in a fixed order, and one wave's adds to one copy resolve
+// in a fixed order, so sums are reproducible run to run.  The Gaussian weight exp(-(i^2+j^2)/(2 s^2)) is
+// taken as E[|i|]*E[|j|] from a per-keypoint table of E[k] = exp(-k^2/(2 s^2)).  Two passes of the circular
 // [1/4 1/2 1/4] filter (sift.cpp:1209-1221), the maximum (sift.cpp:1231-1240) and the peak test with
 // parabolic refinement (sift.cpp:1280-1307) run on lanes 0..35.
-constexpr int kOriStride = 65; // doubles per bin row: 64 lanes + 1 pad (conflict-free column sums)
-constexpr int kOriWaveDoubles = kOriBins * kOriStride + 64;
+constexpr int kOriCopies = 4;
 
 template <typename T>
 __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, size_t kp_img,
@@ -35,10 +43,12 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
                                                 unsigned long long *peak_words, size_t pw_img,
                                                 unsigned int *chunk_sums, size_t chunks_img, unsigned int cap)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ double hist[4][kOriCopies][64];
+    __shared__ double etab[4][64];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    double *hl = reinterpret_cast<double *>(smem_raw) + (size_t)wave * kOriWaveDoubles;
-    double *hs = hl + kOriBins * kOriStride;
+    double *hs = hist[wave][0];
+    double *hc = hist[wave][lane & (kOriCopies - 1)];
+    double *E = etab[wave];
     const int b = blockIdx.y;
     const unsigned int n = min(kp_count[b], cap);
     const double PI2 = 2.0 * SG_PI;
@@ -46,39 +56,51 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
     for (unsigned int j0 = blockIdx.x * 4u; j0 < n; j0 += gridDim.x * 4u) {
         const unsigned int j = j0 + wave;
         const bool active = j < n;
+        KpRec r;
+        int radius = 0;
+        double econs = 0.0;
+#pragma unroll
+        for (int q = 0; q < kOriCopies; q++)
+            hist[wave][q][lane] = 0.0;
         if (active) {
-            const KpRec r = kp[(size_t)b * kp_img + kp_src[(size_t)b * src_img + j]];
+            r = kp[(size_t)b * kp_img + kp_src[(size_t)b * src_img + j]];
+            radius = (int)rint(3.0 * 1.5 * r.oscale); // ORI_WINDOW_RADIUS * octave_scale
+            const double sig = 1.5 * r.oscale;        // ORI_SIGMA_TIMES * octave_scale
+            econs = -1.0 / (2.0 * sig * sig);
+            E[lane] = exp((lane * lane) * econs);
+        }
+        __syncthreads();
+        if (active) {
             const int o = r.octave;
             const T *g = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o];
             const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
-            const int radius = (int)rint(3.0 * 1.5 * r.oscale); // ORI_WINDOW_RADIUS * octave_scale
-            const double sig = 1.5 * r.oscale;                   // ORI_SIGMA_TIMES * octave_scale
-            const double econs = -1.0 / (2.0 * sig * sig);
-#pragma unroll 4
-            for (int q = 0; q < kOriBins; q++)
-                hl[q * kOriStride + lane] = 0.0;
             const int W = 2 * radius + 1, total = W * W;
+            const bool use_tab = radius < 64;
+            // sample s -> (i = s / W - radius: x offset, the reference's outer loop; jj = s % W - radius: y offset)
+            int qi = lane / W, qj = lane - qi * W;
+            const int dq = 64 / W, dr = 64 - dq * W;
             for (int s = lane; s < total; s += 64) {
-                int i = s / W - radius;  // x offset (outer loop of the reference)
-                int jj = s % W - radius; // y offset
+                const int i = qi - radius, jj = qj - radius;
                 double dx, dy;
                 if (grad_at(g, rows, cols, pitch, r.x + i, r.y + jj, dx, dy)) {
-                    double mag = sqrt(dx * dx + dy * dy);
-                    double ori = atan2(dy, dx);
-                    double weight = exp((i * i + jj * jj) * econs);
+                    double mag = sg_sqrt(dx * dx + dy * dy);
+                    double ori = sg_atan2(dy, dx);
+                    double weight = use_tab ? E[abs(i)] * E[abs(jj)] : exp((i * i + jj * jj) * econs);
                     int bin = (int)rint(kOriBins * (SG_PI - ori) / PI2);
                     bin = bin < kOriBins ? bin : 0;
-                    hl[bin * kOriStride + lane] += mag * weight;
+                    lds_add(&hc[bin], mag * weight);
+                }
+                qi += dq;
+                qj += dr;
+                if (qj >= W) {
+                    qj -= W;
+                    qi++;
                 }
             }
         }
         __syncthreads();
-        if (active && lane < kOriBins) {
-            double acc = 0.0;
-            for (int l = 0; l < 64; l++)
-                acc += hl[lane * kOriStride + l];
-            hs[lane] = acc;
-        }
+        if (active && lane < kOriBins)
+            hs[lane] = ((hist[wave][0][lane] + hist[wave][1][lane]) + hist[wave][2][lane]) + hist[wave][3][lane];
         __syncthreads();
         double c = 0.0;
 #pragma unroll
@@ -127,28 +149,33 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
                    size_t chunks_img_stride, unsigned int cap, int B, int prec, hipStream_t s)
 {
     unsigned int blocks = (cap + 3) / 4;
-    if (blocks > 2048)
-        blocks = 2048;
+    if (blocks > 4096)
+        blocks = 4096;
     dim3 g(blocks, B);
-    size_t lds = sizeof(double) * 4 * kOriWaveDoubles;
     if (prec == SG_F64)
-        orient_k<double><<<g, 256, lds, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, kp_count, ori_tmp,
-                                             ori_img_stride, peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap);
+        orient_k<double><<<g, 256, 0, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, kp_count, ori_tmp,
+                                           ori_img_stride, peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap);
     else
-        orient_k<float><<<g, 256, lds, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, kp_count, ori_tmp,
-                                            ori_img_stride, peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap);
+        orient_k<float><<<g, 256, 0, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, kp_count, ori_tmp,
+                                          ori_img_stride, peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap);
 }
 
 // ---- descriptors -----------------------------------------------------------------------------------------
-// One 256-thread workgroup per feature.  CalculateDescrHist + InterpHistEntry (sift.cpp:1352-1535): the
-// threads walk the (2r+1)^2 window, accepted samples spread trilinearly into a wave-private 4x4x8 histogram
-// with LDS double atomics; the four wave histograms are added in wave order.  HistToDescriptor
-// (sift.cpp:1567-1597): normalise, clamp at 0.2, normalise, min(255,(int)(512 v)).
+// One 256-thread workgroup per feature.  CalculateDescrHist + InterpHistEntry (sift.cpp:1352-1535).
+// Pass 1 walks the (2r+1)^2 window with a cheap float test and queues, per wave, the samples that may lie
+// in the rotated 4x4 grid (a superset: the float test has a margin); pass 2 takes the queued samples 64 at
+// a time, repeats the reference's acceptance test in double and spreads each accepted sample trilinearly
+// into wave-private 4x4x8 histograms with LDS double atomics (four copies per wave, lane & 3, added in a
+// fixed order), so that the expensive part runs with full lanes.  Against the reference's per-sample
+// formulas two things are algebraically regrouped (results agree to ~1e-15 relative): the rotated
+// coordinates multiply by 1/shw instead of dividing, and the window weight exp(-(rx^2+ry^2)/8), with
+// rx^2+ry^2 = (i^2+j^2)/shw^2, is E[|i|]*E[|j|] from a per-feature table E[k] = exp(-k^2/(8 shw^2)).
+// HistToDescriptor (sift.cpp:1567-1597): normalise, clamp at 0.2, normalise, min(255,(int)(512 v)).
 
-__device__ __forceinline__ void lds_add(double *p, double v)
-{
-    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
+constexpr int kDescRoundIters = 24;              // pass-1 iterations per round
+constexpr int kDescQueue = kDescRoundIters * 64; // queue entries per wave
+constexpr int kDescCopies = 4;
+constexpr int kDescTab = 128;
 
 __device__ __forceinline__ double block_sum_128(double v, double *red, int tid)
 {
@@ -171,9 +198,11 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
                                                uint8_t *desc, size_t desc_img, double *prequant, size_t pq_img,
                                                double *fscale, size_t fs_img, unsigned int cap)
 {
-    __shared__ double hist[4][128];
+    __shared__ double hist[4 * kDescCopies][128];
+    __shared__ double etab[kDescTab];
     __shared__ double red[4];
-    const int tid = threadIdx.x, wave = tid >> 6;
+    __shared__ unsigned short queue[4][kDescQueue];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int b = blockIdx.y;
     const unsigned int n = min(feat_count[b], cap);
     const double PI2 = SG_PI * 2;
@@ -187,35 +216,76 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
         const T *g = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o];
         const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
 
-        double *hflat = &hist[0][0]; // 512 doubles, 2 per thread
-        hflat[tid] = 0.0;
-        hflat[tid + 256] = 0.0;
-        __syncthreads();
+        double *hflat = &hist[0][0]; // 16 x 128 doubles, 8 per thread
+#pragma unroll
+        for (int q = 0; q < 4 * kDescCopies * 128 / 256; q++)
+            hflat[tid + 256 * q] = 0.0;
 
         const double cos_ori = cos(ori), sin_ori = sin(ori);
-        const double conste = -1.0 / (2 * (0.5 * 4) * (0.5 * 4));
-        const double shw = 3 * r.oscale;                           // DESCR_SCALE_ADJUST * octave_scale
+        const double shw = 3 * r.oscale;                             // DESCR_SCALE_ADJUST * octave_scale
+        const double inv_shw = 1.0 / shw;
         const int radius = (int)((shw * sqrt(2.0) * (4 + 1)) / 2.0); // truncating cast (sift.cpp:1488)
         const int W = 2 * radius + 1, total = W * W;
-        double *h = hist[wave];
-        for (int s = tid; s < total; s += 256) {
-            const int i = s / W - radius;  // y offset (outer loop of the reference)
-            const int jj = s % W - radius; // x offset
-            double rot_x = (cos_ori * jj - sin_ori * i) / shw;
-            double rot_y = (sin_ori * jj + cos_ori * i) / shw;
-            double xbin = rot_x + 4 / 2 - 0.5;
-            double ybin = rot_y + 4 / 2 - 0.5;
-            if (xbin > -1.0 && xbin < 4 && ybin > -1.0 && ybin < 4) {
-                double dx, dy;
-                if (grad_at(g, rows, cols, pitch, r.x + jj, r.y + i, dx, dy)) {
-                    double grad_mag = sqrt(dx * dx + dy * dy);
-                    double grad_ori = (SG_PI - atan2(dy, dx)) - ori;
+        const double wcons = -0.125 * inv_shw * inv_shw; // -1/(2*(0.5*4)^2) / shw^2
+        const bool use_tab = radius < kDescTab;
+        if (tid < kDescTab)
+            etab[tid] = exp((tid * tid) * wcons);
+        const float cf = (float)cos_ori, sf = (float)sin_ori, inv_shw_f = (float)inv_shw;
+        double *h = hist[wave * kDescCopies + (lane & (kDescCopies - 1))];
+        unsigned short *q = queue[wave];
+        // sample s -> (i = s / W - radius: y offset, the reference's outer loop; jj = s % W - radius: x offset)
+        int qi = tid / W, qj = tid - qi * W;
+        const int dq = 256 / W, dr = 256 - dq * W;
+        __syncthreads();
+        for (int base = 0; base < total; base += 256 * kDescRoundIters) {
+            // pass 1: float pre-test with a margin, pixel validity, wave-ordered queue
+            int count = 0;
+            const int round_end = min(total, base + 256 * kDescRoundIters);
+            const int iters = (round_end - base + 255) / 256;
+            for (int it = 0; it < iters; it++) {
+                const int s = base + it * 256 + tid;
+                bool cand = false;
+                const int i = qi - radius, jj = qj - radius;
+                if (s < round_end) {
+                    float rx = (cf * jj - sf * i) * inv_shw_f, ry = (sf * jj + cf * i) * inv_shw_f;
+                    const int x = r.x + jj, y = r.y + i;
+                    cand = rx > -2.5001f && rx < 2.5001f && ry > -2.5001f && ry < 2.5001f && x > 0 && x < cols - 1 &&
+                           y > 0 && y < rows - 1;
+                }
+                unsigned long long m = __ballot(cand);
+                if (cand) {
+                    int pos = count + __popcll(m & ((1ull << lane) - 1ull));
+                    q[pos] = (unsigned short)(((i + radius) << 8) | (jj + radius));
+                }
+                count += __popcll(m);
+                qi += dq;
+                qj += dr;
+                if (qj >= W) {
+                    qj -= W;
+                    qi++;
+                }
+            }
+            __syncthreads();
+            // pass 2: double arithmetic on the queued samples
+            for (int e = lane; e < count; e += 64) {
+                const unsigned int pk = q[e];
+                const int i = (int)(pk >> 8) - radius, jj = (int)(pk & 255u) - radius;
+                double rot_x = (cos_ori * jj - sin_ori * i) * inv_shw;
+                double rot_y = (sin_ori * jj + cos_ori * i) * inv_shw;
+                double xbin = rot_x + 4 / 2 - 0.5;
+                double ybin = rot_y + 4 / 2 - 0.5;
+                if (xbin > -1.0 && xbin < 4 && ybin > -1.0 && ybin < 4) {
+                    const T *p = g + (size_t)(r.y + i) * pitch + (r.x + jj); // validity was tested in pass 1
+                    double dx = (double)p[1] - (double)p[-1];
+                    double dy = (double)p[pitch] - (double)p[-pitch];
+                    double grad_mag = sg_sqrt(dx * dx + dy * dy);
+                    double grad_ori = (SG_PI - sg_atan2(dy, dx)) - ori;
                     while (grad_ori < 0.0)
                         grad_ori += PI2;
                     while (grad_ori >= PI2)
                         grad_ori -= PI2;
                     double obin = grad_ori * (8 / PI2);
-                    double weight = exp(conste * (rot_x * rot_x + rot_y * rot_y));
+                    double weight = use_tab ? etab[abs(i)] * etab[abs(jj)] : exp((i * i + jj * jj) * wcons);
                     double mag = grad_mag * weight;
                     // InterpHistEntry
                     int r0 = (int)floor(ybin), c0 = (int)floor(xbin), o0 = (int)floor(obin);
@@ -232,7 +302,7 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
                                     double v_c = v_r * ((cc == 0) ? 1.0 - d_c : d_c);
 #pragma unroll
                                     for (int oo = 0; oo <= 1; oo++) {
-                                        int ob = (o0 + oo) % 8;
+                                        int ob = (o0 + oo) & 7;
                                         double v_o = v_c * ((oo == 0) ? 1.0 - d_o : d_o);
                                         lds_add(&h[(rb * 4 + cb) * 8 + ob], v_o);
                                     }
@@ -242,11 +312,14 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
                     }
                 }
             }
+            __syncthreads();
         }
-        __syncthreads();
         double v = 0.0;
-        if (tid < 128)
-            v = ((hist[0][tid] + hist[1][tid]) + hist[2][tid]) + hist[3][tid];
+        if (tid < 128) {
+#pragma unroll
+            for (int q2 = 0; q2 < 4 * kDescCopies; q2++)
+                v += hist[q2][tid];
+        }
         double len_sq = block_sum_128(tid < 128 ? v * v : 0.0, red, tid);
         double len_inv = 1.0 / sqrt(len_sq);
         v *= len_inv;
@@ -258,12 +331,12 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
         if (tid < 128) {
             if (prequant)
                 prequant[(size_t)b * pq_img + (size_t)f * 128 + tid] = v;
-            int q = 0;
+            int qv = 0;
             if (v == v) { // an all-zero window gives 0/0; keep such a descriptor at zero
-                q = (int)(512.0 * v); // INT_DESCR_FCTR, truncating
-                q = q < 255 ? q : 255;
+                qv = (int)(512.0 * v); // INT_DESCR_FCTR, truncating
+                qv = qv < 255 ? qv : 255;
             }
-            desc[(size_t)b * desc_img + (size_t)f * 128 + tid] = (uint8_t)q;
+            desc[(size_t)b * desc_img + (size_t)f * 128 + tid] = (uint8_t)qv;
         }
         if (tid == 0)
             fscale[(size_t)b * fs_img + f] = r.scale;
@@ -294,40 +367,84 @@ void launch_descr(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, c
 // ---- ordering: stable rank by scale -----------------------------------------------------------------------
 // rank(i) = #{ j : scale_j < scale_i  or  (scale_j == scale_i and j < i) } -- the position of feature i in a
 // stable ascending sort by scale (reference sift/sift.cpp:1640-1643,1703 sorts by scale alone).
-__global__ __launch_bounds__(256) void rank_k(const double *fscale, size_t fs_img, const unsigned int *feat_count,
-                                              unsigned int *rank, size_t rank_img, unsigned int cap)
+// Scales are positive doubles, so their bit patterns order like their values; the top bits (exponent and 10
+// mantissa bits, clamped) give a monotone bucket index.  Features are counted per bucket, the counts are
+// scanned, indices are scattered into per-bucket lists (in any order), and each feature then counts the
+// smaller keys inside its own bucket only: rank = bucket offset + that count.
+
+__device__ __forceinline__ unsigned int rank_bucket(double s)
 {
-    __shared__ double sc[256];
-    const int b = blockIdx.y, tid = threadIdx.x;
+    long long k = (__double_as_longlong(s) >> 42) - (0x3FE0000000000000ll >> 42); // 0.5 -> 0
+    k = k < 0 ? 0 : (k >= kRankBuckets ? kRankBuckets - 1 : k);
+    return (unsigned int)k;
+}
+
+__global__ __launch_bounds__(256) void rank_hist_k(const double *fscale, size_t fs_img, const unsigned int *feat_count,
+                                                   unsigned int *bcount, size_t bc_img, unsigned int cap)
+{
+    const int b = blockIdx.y;
     const unsigned int n = min(feat_count[b], cap);
-    if (blockIdx.x * 256u >= n)
-        return;
-    const double *fsb = fscale + (size_t)b * fs_img;
-    const unsigned int i = blockIdx.x * 256u + tid;
-    const double my = i < n ? fsb[i] : 0.0;
-    unsigned int cnt = 0;
-    for (unsigned int base = 0; base < n; base += 256) {
-        unsigned int j = base + tid;
-        sc[tid] = j < n ? fsb[j] : 0.0;
-        __syncthreads();
-        unsigned int m = min(256u, n - base);
-        for (unsigned int q = 0; q < m; q++) {
-            double s = sc[q];
-            cnt += (s < my || (s == my && base + q < i)) ? 1u : 0u;
-        }
-        __syncthreads();
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u)
+        atomicAdd(&bcount[(size_t)b * bc_img + rank_bucket(fscale[(size_t)b * fs_img + i])], 1u);
+}
+
+__global__ __launch_bounds__(256) void rank_scatter_k(const double *fscale, size_t fs_img,
+                                                      const unsigned int *feat_count, const unsigned int *boff,
+                                                      unsigned int *bcursor, size_t bc_img, unsigned int *blist,
+                                                      size_t bl_img, unsigned int cap)
+{
+    const int b = blockIdx.y;
+    const unsigned int n = min(feat_count[b], cap);
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        unsigned int k = rank_bucket(fscale[(size_t)b * fs_img + i]);
+        unsigned int pos = boff[(size_t)b * bc_img + k] + atomicAdd(&bcursor[(size_t)b * bc_img + k], 1u);
+        blist[(size_t)b * bl_img + pos] = i;
     }
-    if (i < n)
-        rank[(size_t)b * rank_img + i] = cnt;
+}
+
+__global__ __launch_bounds__(256) void rank_count_k(const double *fscale, size_t fs_img, const unsigned int *feat_count,
+                                                    const unsigned int *boff, size_t bc_img,
+                                                    const unsigned int *blist, size_t bl_img, unsigned int *rank,
+                                                    size_t rank_img, unsigned int cap)
+{
+    const int b = blockIdx.y;
+    const unsigned int n = min(feat_count[b], cap);
+    const double *fsb = fscale + (size_t)b * fs_img;
+    const unsigned int *bl = blist + (size_t)b * bl_img;
+    for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const double my = fsb[i];
+        const unsigned int k = rank_bucket(my);
+        const unsigned int start = boff[(size_t)b * bc_img + k];
+        const unsigned int end = k + 1 < (unsigned int)kRankBuckets ? boff[(size_t)b * bc_img + k + 1] : n;
+        unsigned int cnt = 0;
+        for (unsigned int p = start; p < end; p++) {
+            const unsigned int j = bl[p];
+            const double s = fsb[j];
+            cnt += (s < my || (s == my && j < i)) ? 1u : 0u;
+        }
+        rank[(size_t)b * rank_img + i] = start + cnt;
+    }
 }
 
 void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
-                 size_t rank_img_stride, unsigned int cap, int B, hipStream_t s)
+                 size_t rank_img_stride, unsigned int *bwork, unsigned int *blist, unsigned int *scratch_totals,
+                 unsigned int *overflow_dummy, unsigned int cap, int B, hipStream_t s)
 {
     if (cap == 0)
         return;
-    dim3 g((cap + 255) / 256, B);
-    rank_k<<<g, 256, 0, s>>>(fscale, fs_img_stride, feat_count, rank, rank_img_stride, cap);
+    // bwork: per image [2][kRankBuckets]: counts (scanned in place to offsets), then scatter cursors
+    const size_t bc_img = 2 * (size_t)kRankBuckets;
+    (void)hipMemsetAsync(bwork, 0, sizeof(unsigned int) * bc_img * B, s);
+    unsigned int blocks = (cap + 255) / 256;
+    if (blocks > 256)
+        blocks = 256;
+    dim3 g(blocks, B);
+    rank_hist_k<<<g, 256, 0, s>>>(fscale, fs_img_stride, feat_count, bwork, bc_img, cap);
+    launch_scan(bwork, bc_img, kRankBuckets, scratch_totals, 0xffffffffu, overflow_dummy, B, s);
+    rank_scatter_k<<<g, 256, 0, s>>>(fscale, fs_img_stride, feat_count, bwork, bwork + kRankBuckets, bc_img, blist,
+                                     cap, cap);
+    rank_count_k<<<g, 256, 0, s>>>(fscale, fs_img_stride, feat_count, bwork, bc_img, blist, cap, rank, rank_img_stride,
+                                   cap);
 }
 
 // ---- output packing ------------------------------------------------------------------------------------------

@@ -38,9 +38,11 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
     const bool x_ok = x < cols - kBorder;
     const int xc = x_ok ? x : cols - kBorder - 1; // clamped column for loads; results masked by x_ok
     const int y_begin = kBorder + (blockIdx.y * 4 + wave) * RS;
-    if (y_begin >= rows - kBorder)
-        return;
     const int y_end = min(y_begin + RS, rows - kBorder);
+    __shared__ unsigned int blk_ctr[3];
+    if (threadIdx.x < 3)
+        blk_ctr[threadIdx.x] = 0;
+    __syncthreads();
     const size_t img = (size_t)b * tab.img_stride[o];
     const int nrows = tab.nrows[o], wpr = tab.wpr[o];
     unsigned long long *wbase = words + (size_t)b * words_img + tab.wbase[o];
@@ -72,8 +74,10 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
     };
 
     unsigned int n00 = 0, n0 = 0, n1 = 0;
-    load_row(0, y_begin - 1);
-    load_row(1, y_begin);
+    if (y_begin < y_end) {
+        load_row(0, y_begin - 1);
+        load_row(1, y_begin);
+    }
     for (int y = y_begin; y < y_end; y++) {
         load_row(2, y + 1);
         // per-level 3x3 max and min
@@ -125,12 +129,15 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
             }
         }
     }
-    if (lane == 0) {
-        unsigned long long *ctr = counters + (size_t)b * 8;
-        atomicAdd(&ctr[0], (unsigned long long)n00 * 3ull); // one count per layer
-        atomicAdd(&ctr[1], (unsigned long long)n0);
-        atomicAdd(&ctr[2], (unsigned long long)n1);
+    // counters: one LDS add per wave, then one global add per block and counter
+    if (lane == 0 && n00) {
+        atomicAdd(&blk_ctr[0], n00 * 3u); // one count per layer
+        atomicAdd(&blk_ctr[1], n0);
+        atomicAdd(&blk_ctr[2], n1);
     }
+    __syncthreads();
+    if (threadIdx.x < 3 && blk_ctr[threadIdx.x])
+        atomicAdd(&counters[(size_t)b * 8 + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
 }
 
 void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words, size_t words_img_stride,

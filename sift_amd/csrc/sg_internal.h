@@ -16,6 +16,7 @@ constexpr int kMaxTaps = 2 * kMaxFastRadius + 1;
 constexpr int kBorder = 5;        // IMG_BORDER, sift.h:58
 constexpr int kChunkWords = 1024; // bitmap words per compaction chunk
 constexpr int kOriBins = 36;
+constexpr int kRankBuckets = 16384; // 16 binades x 1024 mantissa steps of the scale key
 
 // One image plane (or a batch of them): element pointer, geometry in elements.
 struct Plane {
@@ -92,8 +93,10 @@ void launch_descr(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, c
                   const unsigned int *feat_count, const double *ori_tmp, size_t ori_img_stride, uint8_t *desc,
                   size_t desc_img_stride, double *prequant, size_t pq_img_stride, double *fscale,
                   size_t fs_img_stride, unsigned int cap, int B, int prec, hipStream_t s);
+// bwork: [B][2][kRankBuckets] scratch, blist: [B][cap] scratch, scratch_totals: [B], overflow_dummy: [1]
 void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
-                 size_t rank_img_stride, unsigned int cap, int B, hipStream_t s);
+                 size_t rank_img_stride, unsigned int *bwork, unsigned int *blist, unsigned int *scratch_totals,
+                 unsigned int *overflow_dummy, unsigned int cap, int B, hipStream_t s);
 // mode 0: packed features (sg_packed_feature) at out + b*out_img_stride*144; mode 1: sg_keypoint records.
 void launch_pack(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src, size_t src_img_stride,
                  const unsigned int *feat_src, size_t fsrc_img_stride, const unsigned int *feat_count,

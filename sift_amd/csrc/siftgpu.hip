@@ -64,6 +64,7 @@ struct sg_ctx {
     unsigned int *d_chunks = nullptr; // three arrays per image: detect, valid, peaks
     size_t chunks1 = 0, chunks2 = 0, chunks3 = 0, chunks_total = 0;
     unsigned int *d_cand = nullptr, *d_kpsrc = nullptr, *d_fsrc = nullptr, *d_rank = nullptr;
+    unsigned int *d_bwork = nullptr, *d_blist = nullptr, *d_rtot = nullptr; // rank scratch
     KpRec *d_kp = nullptr;
     double *d_ori = nullptr, *d_pq = nullptr, *d_fscale = nullptr;
     uint8_t *d_desc = nullptr;
@@ -343,7 +344,8 @@ static void rank_phase(sg_ctx *c, int B)
 {
     unsigned int *n_feat = c->d_counts + 2 * c->B;
     StageScope sc(c, SG_ST_SORT);
-    launch_rank(c->d_fscale, c->feat_cap, n_feat, c->d_rank, c->feat_cap, c->feat_cap, B, c->stream);
+    launch_rank(c->d_fscale, c->feat_cap, n_feat, c->d_rank, c->feat_cap, c->d_bwork, c->d_blist, c->d_rtot,
+                c->d_rtot + c->B, c->feat_cap, B, c->stream);
 }
 
 static void pack_phase(sg_ctx *c, void *out, size_t out_img_stride, unsigned int out_cap, unsigned int *out_counts,
@@ -515,7 +517,7 @@ int sg_destroy(sg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_in, c->d_up, c->d_tmp, c->d_levels, c->d_words, c->d_vwords, c->d_pwords, c->d_chunks,
                     c->d_cand, c->d_kpsrc, c->d_fsrc, c->d_rank, c->d_kp, c->d_ori, c->d_pq, c->d_fscale, c->d_desc,
-                    c->d_counts, c->d_ctr, c->d_overflow, c->d_out, c->d_outcounts};
+                    c->d_counts, c->d_ctr, c->d_overflow, c->d_out, c->d_outcounts, c->d_bwork, c->d_blist, c->d_rtot};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -628,6 +630,9 @@ int sg_create(const sg_params *p, sg_ctx **out)
     ALLOC(c->d_ctr, sizeof(unsigned long long) * 8 * B);
     ALLOC(c->d_overflow, sizeof(unsigned int) * 4);
     ALLOC(c->d_outcounts, sizeof(unsigned int) * B);
+    ALLOC(c->d_bwork, sizeof(unsigned int) * 2 * kRankBuckets * B);
+    ALLOC(c->d_blist, sizeof(unsigned int) * (size_t)c->feat_cap * B);
+    ALLOC(c->d_rtot, sizeof(unsigned int) * (B + 1));
 #undef ALLOC
     (void)hipMemset(c->d_words, 0, sizeof(unsigned long long) * c->words_img * B);
     (void)hipMemset(c->d_vwords, 0, sizeof(unsigned long long) * c->vwords_img * B);

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsiftgpu.so")
+LIB_PATH = os.environ.get("SIFTGPU_LIB") or os.path.join(_HERE, "libsiftgpu.so")
 
 SG_OK, SG_E_INVALID, SG_E_HIP, SG_E_CAPACITY, SG_E_UNSUPPORTED, SG_E_NOMEM = 0, -1, -2, -3, -4, -5
 SG_F64, SG_F32 = 0, 1

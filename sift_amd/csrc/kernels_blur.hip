@@ -181,6 +181,195 @@ __global__ __launch_bounds__(256) void blur_col_k(const T *__restrict__ src, T *
     }
 }
 
+// ---- fused row + column pass ---------------------------------------------------------------------------
+// One launch per blur: a block owns a strip of TW = 64*V columns and walks down a segment of rows.  Every
+// input row is read from HBM once (16 bytes per lane plus the 2R halo columns), row-filtered by one wave
+// through a wave-private LDS image of the raw row, and the row-filtered result enters a ring of LDS rows;
+// the column filter reads the ring.  Per round the four waves take K input rows each (row pass), meet at one
+// barrier, and then produce K vertically adjacent output rows each (column pass) while the loads of the
+// next round are in flight.  The column pass walks the taps outwards from the centre and keeps the K rows'
+// operands in two sliding register windows, so a round costs K + 2R ring reads per wave instead of K(2R+1).
+// Arithmetic and operation order per pixel are those of the two-pass kernels above, so results are
+// bit-identical to them; HBM traffic is one read and one write per pixel.
+template <typename T, int R, int V, int K>
+__global__ __launch_bounds__(256) void blur_fused_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols,
+                                                    int spitch, int dpitch, size_t simg, size_t dimg, int seg,
+                                                    Taps<T> taps)
+{
+    typedef typename VecOf<T, V>::type vec_t;
+    constexpr int TW = 64 * V;
+    constexpr int ROUND = 4 * K;                       // rows per block per round
+    constexpr int RING = 2 * R + 2 * ROUND;            // rows readable this round + rows written next round
+    constexpr int NWIN = (V + 2 * R + V - 1) / V;      // vectors per row window
+    constexpr int RAWW = (R + TW + NWIN * V + 3) & ~3; // raw row image incl. read overshoot, 16-byte rows
+    constexpr int KR = 2;                              // raw rows staged at a time
+    static_assert(K % KR == 0, "K must be a multiple of the raw staging depth");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *ring = reinterpret_cast<T *>(smem_raw); // [RING][TW]
+    T *rawbase = ring + (size_t)RING * TW;     // [4][KR][RAWW]
+    // the wave index as a scalar, so that ring-slot arithmetic stays on the scalar unit
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    T *raw = rawbase + (size_t)wave * KR * RAWW;
+    const int x0 = blockIdx.x * TW;
+    const int ys = blockIdx.y * seg;
+    const int ye = min(ys + seg, rows);
+    const int xb = x0 + lane * V;
+    const T *s = src + blockIdx.z * simg;
+    T *d = dst + blockIdx.z * dimg;
+    const int n_rounds = (ye - ys + 2 * R + ROUND - 1) / ROUND;
+    const bool full = xb + V <= cols;
+    const int hx = lane < R ? x0 - R + lane : x0 + TW + (lane - R); // halo column of this lane (lanes < 2R)
+    const int hxr = reflect101(hx, cols);
+
+    vec_t mainv[K];
+    T halo[K];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            const int m = ROUND * t + K * wave + k;
+            const int yy = reflect101(ys - R + m, rows);
+            const T *sr = s + (size_t)yy * spitch;
+            if (full) {
+                mainv[k] = *reinterpret_cast<const vec_t *>(sr + xb);
+            } else {
+                T *pv = reinterpret_cast<T *>(&mainv[k]);
+#pragma unroll
+                for (int q = 0; q < V; q++)
+                    pv[q] = sr[reflect101(xb + q, cols)];
+            }
+            halo[k] = lane < 2 * R ? sr[hxr] : (T)0;
+        }
+    };
+    auto ring_at = [&](int slot) { // slot in [0, 2*RING)
+        slot = slot >= RING ? slot - RING : slot;
+        return ring + (size_t)slot * TW + lane * V;
+    };
+
+    fetch(0);
+    int slot_a = (K * wave) % RING;                                // slot of this wave's first input row of the round
+    int slot_b = ((RING - (2 * R) % RING) % RING + K * wave) % RING; // slot of virtual row n = -2R + K*wave
+    for (int t = 0; t < n_rounds; t++) {
+        // ---- row pass: this wave's K input rows, KR at a time through the raw image ----
+#pragma unroll
+        for (int kb = 0; kb < K; kb += KR) {
+#pragma unroll
+            for (int k = 0; k < KR; k++) {
+                // element stores: the image starts R columns left of the strip, so this address is 16-byte
+                // aligned only when R is a multiple of V; the window reads below are the aligned side
+                const T *pm = reinterpret_cast<const T *>(&mainv[kb + k]);
+#pragma unroll
+                for (int q = 0; q < V; q++)
+                    raw[k * RAWW + R + lane * V + q] = pm[q];
+                if (lane < 2 * R)
+                    raw[k * RAWW + (lane < R ? lane : TW + lane)] = halo[kb + k];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // same-wave LDS hand-off between lanes
+#pragma unroll
+            for (int k = 0; k < KR; k++) {
+                vec_t o;
+                T *po = reinterpret_cast<T *>(&o);
+                T prev[V]; // last element(s) of the previous vector, for the outputs that straddle vectors
+#pragma unroll
+                for (int q = 0; q < NWIN; q++) {
+                    vec_t v = *reinterpret_cast<const vec_t *>(raw + k * RAWW + lane * V + q * V);
+                    const T *pv = reinterpret_cast<const T *>(&v);
+                    // window element index e = q*V + j feeds output v_out with tap tt = e - v_out
+#pragma unroll
+                    for (int j = 0; j < V; j++) {
+                        const int e = q * V + j;
+#pragma unroll
+                        for (int vo = 0; vo < V; vo++) {
+                            const int tt = e - vo;
+                            if (tt == 0)
+                                po[vo] = taps.k[0] * pv[j];
+                            else if (tt > 0 && tt <= 2 * R)
+                                po[vo] += taps.k[tt] * pv[j];
+                        }
+                    }
+                    (void)prev;
+                }
+                int sl = slot_a + kb + k;
+                *reinterpret_cast<vec_t *>(ring_at(sl)) = o;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the raw image is overwritten next
+        }
+        if (t + 1 < n_rounds)
+            fetch(t + 1);
+        __syncthreads();
+        // ---- column pass: K adjacent output rows per wave from the ring ----
+        const int n0 = ROUND * t - 2 * R + K * wave; // first output row (segment-relative); ring rows n0 .. n0+K-1+2R
+        if (n0 + K > 0 && ys + n0 < ye && xb < cols) {
+            vec_t acc[K], up[K], dn[K];
+            // centres ring[R + j]
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                vec_t c = *reinterpret_cast<const vec_t *>(ring_at(slot_b + R + j));
+                const T *pc = reinterpret_cast<const T *>(&c);
+                T *pa = reinterpret_cast<T *>(&acc[j]);
+#pragma unroll
+                for (int e = 0; e < V; e++)
+                    pa[e] = taps.k[R] * pc[e];
+                if (j + 1 < K)
+                    dn[j + 1] = c; // ring[R + (j+1) - 1]
+                if (j > 0)
+                    up[j - 1] = c; // ring[R + (j-1) + 1]
+            }
+            up[K - 1] = *reinterpret_cast<const vec_t *>(ring_at(slot_b + R + K));
+            dn[0] = *reinterpret_cast<const vec_t *>(ring_at(slot_b + R - 1));
+#pragma unroll
+            for (int tt = 1; tt <= R; tt++) {
+#pragma unroll
+                for (int j = 0; j < K; j++) {
+                    const T *pu = reinterpret_cast<const T *>(&up[j]), *pd = reinterpret_cast<const T *>(&dn[j]);
+                    T *pa = reinterpret_cast<T *>(&acc[j]);
+#pragma unroll
+                    for (int e = 0; e < V; e++)
+                        pa[e] += taps.k[R + tt] * (pu[e] + pd[e]);
+                }
+                if (tt < R) {
+                    // slide: up[j] <- ring[R + j + tt + 1], dn[j] <- ring[R + j - tt - 1]
+#pragma unroll
+                    for (int j = 0; j + 1 < K; j++)
+                        up[j] = up[j + 1];
+                    up[K - 1] = *reinterpret_cast<const vec_t *>(ring_at(slot_b + R + K + tt));
+#pragma unroll
+                    for (int j = K - 1; j > 0; j--)
+                        dn[j] = dn[j - 1];
+                    dn[0] = *reinterpret_cast<const vec_t *>(ring_at(slot_b + R - 1 - tt));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < K; j++) {
+                const int n = n0 + j, y = ys + n;
+                if (n >= 0 && y < ye) {
+                    T *dr = d + (size_t)y * dpitch;
+                    if (full) {
+                        *reinterpret_cast<vec_t *>(dr + xb) = acc[j];
+                    } else {
+                        const T *pa = reinterpret_cast<const T *>(&acc[j]);
+#pragma unroll
+                        for (int e = 0; e < V; e++)
+                            if (xb + e < cols)
+                                dr[xb + e] = pa[e];
+                    }
+                }
+            }
+        }
+        slot_a += ROUND;
+        slot_a = slot_a >= RING ? slot_a - RING : slot_a;
+        slot_b += ROUND;
+        slot_b = slot_b >= RING ? slot_b - RING : slot_b;
+    }
+}
+
+template <typename T, int R, int V, int K>
+static size_t fused_lds_bytes()
+{
+    constexpr int TW = 64 * V, ROUND = 4 * K, RING = 2 * R + 2 * ROUND, KR = 2;
+    constexpr int NWIN = (V + 2 * R + V - 1) / V, RAWW = (R + TW + NWIN * V + 3) & ~3;
+    return sizeof(T) * ((size_t)RING * TW + (size_t)4 * KR * RAWW);
+}
+
 // ---- any-radius fallback (one thread per output pixel, taps in global memory) ------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void blur_row_any_k(const T *src, T *dst, int rows, int cols, int spitch,
@@ -334,6 +523,55 @@ static void col_dispatch(const Plane &src, const Plane &dst, int B, const double
     }
     }
 #undef SG_COL_CASE
+}
+
+template <typename T, int V>
+static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s)
+{
+    const int rows = src.rows, cols = src.cols;
+    if (n <= 1 || cols == 1 || rows == 1)
+        return false;
+    int R = bucket_radius(n / 2);
+    if (R < 0)
+        return false;
+    constexpr int TW = 64 * V;
+    constexpr int KF = 4; // rows per wave per round of the fused kernel
+    const int strips = (cols + TW - 1) / TW;
+    // segment length: several thousand blocks so that the chip stays full through the tail, but segments
+    // long enough that the 2R halo rows (re-read and row-filtered again) stay a small share on large planes
+    long long want = 6144;
+    long long per_row_blocks = (long long)strips * B;
+    int seg = (int)(((long long)rows * per_row_blocks + want - 1) / want);
+    if (seg < 16)
+        seg = 16;
+    if (seg > rows)
+        seg = rows;
+    seg = (seg + 4 * KF - 1) / (4 * KF) * (4 * KF);
+    dim3 g(strips, (rows + seg - 1) / seg, B);
+#define SG_FUSED_CASE(RR)                                                                                             \
+    case RR:                                                                                                          \
+        blur_fused_k<T, RR, V, KF><<<g, 256, fused_lds_bytes<T, RR, V, KF>(), s>>>(                                           \
+            (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,      \
+            padded_taps<T>(taps, n, RR));                                                                             \
+        break;
+    switch (R) {
+        SG_FUSED_CASE(5)
+        SG_FUSED_CASE(6)
+        SG_FUSED_CASE(8)
+        SG_FUSED_CASE(10)
+        SG_FUSED_CASE(13)
+    default:
+        return false;
+    }
+#undef SG_FUSED_CASE
+    return true;
+}
+
+bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s)
+{
+    if (prec == SG_F64)
+        return fused_dispatch<double, 2>(src, dst, B, taps, n, s);
+    return fused_dispatch<float, 4>(src, dst, B, taps, n, s);
 }
 
 void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s)

@@ -3,6 +3,10 @@
 #include "sg_internal.h"
 #include "sg_math.h"
 
+#ifndef SG_ABL
+#define SG_ABL 0
+#endif
+
 namespace sg {
 
 #define SG_PI 3.1415926535897932384626433832795 /* CV_PI */
@@ -232,6 +236,9 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
             etab[tid] = exp((tid * tid) * wcons);
         const float cf = (float)cos_ori, sf = (float)sin_ori, inv_shw_f = (float)inv_shw;
         double *h = hist[wave * kDescCopies + (lane & (kDescCopies - 1))];
+#if SG_ABL == 1
+        double abl_acc = 0.0;
+#endif
         unsigned short *q = queue[wave];
         // sample s -> (i = s / W - radius: y offset, the reference's outer loop; jj = s % W - radius: x offset)
         int qi = tid / W, qj = tid - qi * W;
@@ -267,6 +274,9 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
             }
             __syncthreads();
             // pass 2: double arithmetic on the queued samples
+#if SG_ABL == 3
+            count = 0;
+#endif
             for (int e = lane; e < count; e += 64) {
                 const unsigned int pk = q[e];
                 const int i = (int)(pk >> 8) - radius, jj = (int)(pk & 255u) - radius;
@@ -278,8 +288,13 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
                     const T *p = g + (size_t)(r.y + i) * pitch + (r.x + jj); // validity was tested in pass 1
                     double dx = (double)p[1] - (double)p[-1];
                     double dy = (double)p[pitch] - (double)p[-pitch];
+#if SG_ABL == 2
+                    double grad_mag = dx * dx + dy * dy;
+                    double grad_ori = (SG_PI - (dy > 0 ? dx * 8 : -3 + dy * 8)) - ori;
+#else
                     double grad_mag = sg_sqrt(dx * dx + dy * dy);
                     double grad_ori = (SG_PI - sg_atan2(dy, dx)) - ori;
+#endif
                     while (grad_ori < 0.0)
                         grad_ori += PI2;
                     while (grad_ori >= PI2)
@@ -304,7 +319,11 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
                                     for (int oo = 0; oo <= 1; oo++) {
                                         int ob = (o0 + oo) & 7;
                                         double v_o = v_c * ((oo == 0) ? 1.0 - d_o : d_o);
+#if SG_ABL == 1
+                                        abl_acc += v_o;
+#else
                                         lds_add(&h[(rb * 4 + cb) * 8 + ob], v_o);
+#endif
                                     }
                                 }
                             }
@@ -340,6 +359,9 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
         }
         if (tid == 0)
             fscale[(size_t)b * fs_img + f] = r.scale;
+#if SG_ABL == 1
+        if (abl_acc == 123.456) desc[0] = 1;
+#endif
         __syncthreads();
     }
 }

@@ -64,6 +64,9 @@ void launch_vnoise5(uint8_t *dst, int rows, int cols, uint64_t seed, hipStream_t
 // taps: n doubles (host), n odd. Row pass src->tmp, column pass tmp->dst. In-place (src==dst) is allowed.
 void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
 void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
+// Row and column pass in one launch (src != dst). Returns false, launching nothing, where only the two-pass
+// kernels apply (1-pixel-wide or -high planes, radius beyond the fast kernels).
+bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
 
 // ---- detection --------------------------------------------------------------------------------
 void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words, size_t words_img_stride,

@@ -8,6 +8,7 @@
 // never waits inside a batch.
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -76,6 +77,7 @@ struct sg_ctx {
     unsigned int *d_outcounts = nullptr;
 
     bool prof = false;
+    bool fused_blur = true; // one-launch blur; SIFTGPU_BLUR=2pass selects the separate row/column kernels
     StageEvents ev;
     double stage_ms[SG_ST_COUNT];
     unsigned long long stage_launches[SG_ST_COUNT];
@@ -361,6 +363,11 @@ static void pack_phase(sg_ctx *c, void *out, size_t out_img_stride, unsigned int
 // blur src -> dst through the context's row-pass scratch plane
 static void blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, const double *taps, int n, int slot)
 {
+    if (c->fused_blur) {
+        StageScope sc(c, SG_ST_BLUR_COL0 + slot);
+        if (launch_blur_fused(src, dst, B, taps, n, c->prm.precision, c->stream))
+            return;
+    }
     Plane tmp = src;
     tmp.p = c->d_tmp;
     tmp.pitch = src.pitch;
@@ -552,6 +559,10 @@ int sg_create(const sg_params *p, sg_ctx **out)
     c->prm = *p;
     c->B = p->max_batch;
     c->esize = p->precision == SG_F64 ? 8 : 4;
+    {
+        const char *e = getenv("SIFTGPU_BLUR");
+        c->fused_blur = !(e && strcmp(e, "2pass") == 0);
+    }
     memset(c->stage_ms, 0, sizeof c->stage_ms);
     memset(c->stage_launches, 0, sizeof c->stage_launches);
 
@@ -1025,6 +1036,8 @@ int blur_tmp(sg_ctx *c, const Plane &src, const Plane &dst, double sigma)
     int n = gaussian_taps(sigma, taps.data(), 1024);
     if (n < 0)
         return fail(c, SG_E_UNSUPPORTED, "sigma too large");
+    if (c->fused_blur && launch_blur_fused(src, dst, 1, taps.data(), n, c->prm.precision, c->stream))
+        return finish(c);
     TmpPlane tmp(c, src.rows, src.cols);
     if (!tmp.ok())
         return fail(c, SG_E_NOMEM, "out of device memory");

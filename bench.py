@@ -70,6 +70,7 @@ def main():
     import torch
     import torch.distributed as dist
     import sift_amd
+    from sift_amd import dist as sdist
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
@@ -113,9 +114,8 @@ def main():
         ctxs[c].sync()
         pending[c] = False
         if world > 1:
-            h1 = dist.all_gather_into_tensor(g_cnts[c], cnts[c], async_op=True)
-            h2 = dist.all_gather_into_tensor(g_outs[c], outs[c], async_op=True)
-            handles[c] = (h1, h2)
+            _, _, handles[c] = sdist.allgather_features(outs[c], cnts[c], async_op=True, out=g_outs[c],
+                                                        out_counts=g_cnts[c])
 
     def submit(step):
         c = step % nctx

@@ -1,0 +1,111 @@
+// sift_gpu.h -- host C++ interface of the MI355X SIFT path: the entry points of the reference's
+// sift/sift.h (Jia-Baos/SIFT), same names, argument meaning and record layout, backed by libsiftgpu.
+//
+// A program written against the reference includes this header instead of its sift.h and links
+// libsift_host.so + libsiftgpu.so; nothing else changes for the extraction path
+//   Sift / Sift_nointerval and the stage functions ConvertToGray ... DetectionLocalExtrema,
+//   plus CalculateScale, HalfFeatures, OrientationAssignment, DescriptorRepresentation, FeatureCmp
+//   (defined with external linkage in the reference's sift.cpp:1065-1643 though absent from its header)
+//   and the text feature files (write_features / read_features, sift.cpp:1886-1931).
+// Not provided (outside the extraction path): the 8-bit legacy blurs, drawing, pyramid dumps and
+// testInverse3D of the reference (sift.cpp:183-314, 1772-1884, 1934-1960).
+//
+// Like the reference these functions return void and append to the vectors they are given; a failed
+// GPU call leaves the outputs untouched and is reported by SiftLastStatus() / SiftLastError().
+#pragma once
+
+#include <string>
+#include <vector>
+
+#ifdef SIFT_WITH_OPENCV
+#include <opencv2/core/core.hpp>
+#else
+#include "cvmini.h"
+#endif
+
+using cv::Mat; // the reference's header has `using namespace cv` at global scope (sift.h:9-10)
+
+// ---- parameters: the macros of sift/sift.h:16-70, same names and values -------------------------
+typedef double pixel_t;               // pyramid sample type
+#define INIT_SIGMA 0.5                // assumed blur of the input image
+#define SIGMA 1.6                     // blur of octave 0, level 0
+#define INTERVALS 3                   // sampled intervals per octave
+#define RATIO 10                      // principal-curvature ratio of the edge test
+#define MAX_INTERPOLATION_STEPS 5     // sub-pixel refinement moves before a candidate is dropped
+#define DXTHRESHOLD 0.03              // contrast threshold on |D(x)|
+#define ORI_HIST_BINS 36              // orientation histogram bins
+#define ORI_SIGMA_TIMES 1.5           // orientation window sigma = this * octave_scale
+#define ORI_WINDOW_RADIUS 3.0 * ORI_SIGMA_TIMES // orientation window radius factor (unparenthesised as in the reference)
+#define ORI_SMOOTH_TIMES 2            // [1/4 1/2 1/4] passes over the orientation histogram
+#define ORI_PEAK_RATIO 0.8            // peaks above this share of the maximum spawn a feature
+#define FEATURE_ELEMENT_LENGTH 128    // descriptor length
+#define DESCR_HIST_BINS 8             // orientation bins per descriptor cell
+#define IMG_BORDER 5                  // border not scanned for extrema
+#define DESCR_WINDOW_WIDTH 4          // descriptor cells per side
+#define DESCR_SCALE_ADJUST 3          // cell width = this * octave_scale
+#define DESCR_MAG_THR 0.2             // clamp of the normalised descriptor
+#define INT_DESCR_FCTR 512.0          // float -> integer descriptor factor
+
+// ---- records: layout of sift/sift.h:75-110 (Keypoint is 1120 bytes) ---------------------------------
+struct Keypoint {
+    int octave;             // octave of the DoG layer the point was found in
+    int interval;           // layer inside the octave after refinement
+    double offset_interval; // sub-layer offset
+    int x;                  // column in that octave's image
+    int y;                  // row in that octave's image
+    double scale;           // sigma * 2^(octave + (interval+offset)/S), in input-image pixels
+    double dx;              // x in input-image pixels
+    double dy;              // y in input-image pixels
+    double offset_x;        // sub-pixel offsets
+    double offset_y;
+    double octave_scale;    // sigma * 2^((interval+offset)/S): scale inside the octave
+    double ori;             // orientation, radians in [-pi, pi)
+    int descr_length;       // 128 once described
+    double descriptor[FEATURE_ELEMENT_LENGTH]; // integer-valued 0..255
+    double val;             // DoG value at the refined position
+};
+
+struct MatchPoint {
+    int index_1; // feature index in image 1
+    int index_2; // nearest feature in image 2
+};
+
+// ---- image preparation and pyramids (sift.h:115-133) -------------------------------------------------
+void ConvertToGray(const Mat &src, Mat &dst);  // CV_8UC3+ (b,g,r) -> CV_64FC1 in [0,1]
+void DownSample(const Mat &src, Mat &dst);     // every second row and column
+void UpSample(const Mat &src, Mat &dst);       // 2x with the reference's edge replication
+void GaussianSmooth(const Mat &src, Mat &dst, double sigma);
+void CreateInitSmoothGray(const Mat &src, Mat &dst, double sigma = SIGMA);
+void GaussianPyramid(const Mat &src, std::vector<Mat> &gauss_pyr, int octaves, int intervals = INTERVALS,
+                     double sigma = SIGMA);
+void Sub(const Mat &a, const Mat &b, Mat &c);
+void DogPyramid(const std::vector<Mat> &gauss_pyr, std::vector<Mat> &dog_pyr, int octaves, int intervals = INTERVALS);
+
+// ---- detection (sift.h:135-137) ------------------------------------------------------------------------
+void DetectionLocalExtrema(const std::vector<Mat> &dog_pyr, std::vector<Keypoint> &extrema, int octaves,
+                           int intervals = INTERVALS);
+void DetectionLocalExtrema_nointerval(const std::vector<Mat> &dog_pyr, std::vector<Keypoint> &extrema, int octaves,
+                                      int intervals = INTERVALS);
+
+// ---- scale, orientation, descriptors, ordering (sift.cpp:1065-1643) --------------------------------------
+void CalculateScale(std::vector<Keypoint> &features, double sigma = SIGMA, int intervals = INTERVALS);
+void HalfFeatures(std::vector<Keypoint> &features);
+void OrientationAssignment(std::vector<Keypoint> &extrema, std::vector<Keypoint> &features,
+                           const std::vector<Mat> &gauss_pyr);
+void DescriptorRepresentation(std::vector<Keypoint> &features, const std::vector<Mat> &gauss_pyr, int bins, int width);
+bool FeatureCmp(Keypoint &f1, Keypoint &f2);
+
+// ---- drivers (sift.h:139-141) ----------------------------------------------------------------------------
+void Sift(const Mat &src, std::vector<Keypoint> &features, double sigma = SIGMA, int intervals = INTERVALS);
+void Sift_nointerval(const Mat &src, std::vector<Keypoint> &features, double sigma = SIGMA, int intervals = INTERVALS);
+
+// ---- text feature files (sift.h:155-157) -------------------------------------------------------------------
+void read_features(std::vector<Keypoint> &features, const char *file);
+void write_features(const std::vector<Keypoint> &features, const char *file);
+
+// ---- additions of this implementation -----------------------------------------------------------------------
+int SiftLastStatus();            // sg_status of the most recent call on this thread (0 = ok)
+const char *SiftLastError();     // text for it
+void SiftSetDevice(int device);  // HIP device used by later calls on this thread (default 0)
+void SiftSetVerbose(bool on);    // print the reference's progress lines (sift.cpp:1654-1706); default off
+void SiftReleaseContext();       // free this thread's GPU context

@@ -1,0 +1,542 @@
+// sift_host.cpp -- host C++ layer: the reference's free functions (sift/sift.h, sift/sift.cpp) implemented
+// as thin calls into the C ABI of libsiftgpu.  No image arithmetic happens here; this file only
+// marshals cv::Mat / std::vector arguments, manages one GPU context per thread and reproduces the
+// reference's calling conventions (void returns, outputs appended, silent return on bad arguments).
+#include "sift_gpu.h"
+
+#include <cmath>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+
+#include "siftgpu.h"
+
+static_assert(sizeof(Keypoint) == sizeof(sg_keypoint), "Keypoint must match the C ABI record");
+
+namespace {
+
+struct ThreadState {
+    sg_ctx *ctx = nullptr;
+    int max_w = 0, max_h = 0;
+    double sigma = 0;
+    int nointerval = -1;
+    int device = 0;
+    int status = SG_OK;
+    std::string error;
+    bool verbose = false;
+    ~ThreadState()
+    {
+        if (ctx)
+            sg_destroy(ctx);
+    }
+};
+
+thread_local ThreadState tls;
+
+void set_status(int rc, const char *what = nullptr)
+{
+    tls.status = rc;
+    if (rc == SG_OK) {
+        tls.error.clear();
+        return;
+    }
+    tls.error = what ? what : "";
+    if (tls.ctx && tls.error.empty())
+        tls.error = sg_last_error(tls.ctx);
+    if (tls.error.empty())
+        tls.error = sg_strerror(rc);
+}
+
+// A context able to take input images up to w x h (i.e. base planes up to 2w x 2h).
+sg_ctx *context_for(int w, int h, double sigma, int nointerval)
+{
+    if (w < 2)
+        w = 2;
+    if (h < 2)
+        h = 2;
+    const bool fits = tls.ctx && w <= tls.max_w && h <= tls.max_h && sigma == tls.sigma && nointerval == tls.nointerval;
+    if (fits)
+        return tls.ctx;
+    if (tls.ctx) {
+        sg_destroy(tls.ctx);
+        tls.ctx = nullptr;
+    }
+    sg_params p;
+    sg_default_params(&p);
+    p.sigma = sigma;
+    p.nointerval = nointerval;
+    p.max_width = w > tls.max_w ? w : tls.max_w;
+    p.max_height = h > tls.max_h ? h : tls.max_h;
+    p.max_batch = 1;
+    p.device = tls.device;
+    int rc = sg_create(&p, &tls.ctx);
+    if (rc != SG_OK) {
+        tls.ctx = nullptr;
+        tls.max_w = tls.max_h = 0;
+        set_status(rc, "sg_create failed (is a HIP device present? there is no CPU fallback)");
+        return nullptr;
+    }
+    tls.max_w = p.max_width;
+    tls.max_h = p.max_height;
+    tls.sigma = sigma;
+    tls.nointerval = nointerval;
+    return tls.ctx;
+}
+
+// context for stage calls on a plane of cols x rows used as (at most) a base image
+sg_ctx *context_for_plane(int cols, int rows)
+{
+    double sigma = tls.ctx ? tls.sigma : SIGMA;
+    int ni = tls.ctx ? tls.nointerval : 0;
+    return context_for((cols + 1) / 2, (rows + 1) / 2, sigma, ni);
+}
+
+bool is_f64_plane(const Mat &m) { return !m.empty() && m.type() == CV_64FC1; }
+
+// contiguous double view of a CV_64FC1 Mat (copies only when the rows are padded)
+struct PlaneView {
+    const double *p = nullptr;
+    std::vector<double> copy;
+    explicit PlaneView(const Mat &m)
+    {
+        if ((size_t)m.step == (size_t)m.cols * sizeof(double)) {
+            p = reinterpret_cast<const double *>(m.data);
+        } else {
+            copy.resize((size_t)m.rows * m.cols);
+            for (int y = 0; y < m.rows; y++)
+                std::memcpy(&copy[(size_t)y * m.cols], m.data + m.step * (size_t)y, sizeof(double) * (size_t)m.cols);
+            p = copy.data();
+        }
+    }
+};
+
+void octave_dims(int rows, int cols, int octaves, std::vector<int> &r, std::vector<int> &c)
+{
+    r.resize(octaves);
+    c.resize(octaves);
+    for (int o = 0; o < octaves; o++) {
+        if (o == 0) {
+            r[0] = rows;
+            c[0] = cols;
+        } else if (r[o - 1] <= 1 || c[o - 1] <= 1) {
+            r[o] = r[o - 1];
+            c[o] = c[o - 1];
+        } else {
+            r[o] = r[o - 1] / 2;
+            c[o] = c[o - 1] / 2;
+        }
+    }
+}
+
+void run_sift(const Mat &src, std::vector<Keypoint> &features, double sigma, int intervals, int nointerval)
+{
+    if (src.empty() || src.depth() != CV_8U || src.channels() < 3) {
+        set_status(SG_E_INVALID, "Sift needs an 8-bit image with at least 3 interleaved channels (b,g,r)");
+        return;
+    }
+    if (intervals != INTERVALS) {
+        set_status(SG_E_UNSUPPORTED, "only intervals == 3 is supported (the reference hard-wires INTERVALS)");
+        return;
+    }
+    sg_ctx *ctx = context_for(src.cols, src.rows, sigma, nointerval);
+    if (!ctx)
+        return;
+    size_t cap = (size_t)src.cols * src.rows / 40 + 4096, n = 0;
+    std::vector<Keypoint> out(cap);
+    int rc = sg_extract(ctx, src.data, src.cols, src.rows, src.channels(), src.step,
+                        reinterpret_cast<sg_keypoint *>(out.data()), cap, &n);
+    if (rc == SG_E_CAPACITY && n > cap) {
+        cap = n;
+        out.resize(cap);
+        rc = sg_extract(ctx, src.data, src.cols, src.rows, src.channels(), src.step,
+                        reinterpret_cast<sg_keypoint *>(out.data()), cap, &n);
+    }
+    set_status(rc);
+    if (rc != SG_OK)
+        return;
+    if (tls.verbose) { // the reference's progress lines (sift.cpp:984-986, 1654-1706)
+        sg_counters c;
+        sg_read_counters(ctx, 0, &c);
+        std::cout << "rows = " << 2 * src.rows << "  cols = " << 2 * src.cols << "  octaves = " << sg_last_octaves(ctx)
+                  << std::endl;
+        std::cout << "cc00: " << c.cc00 << ", cc0: " << c.cc0 << ", cc1: " << c.cc1 << ", cc2: " << c.cc2
+                  << ", cc3: " << c.cc3 << std::endl;
+        std::cout << "keypoints cout: " << c.cc3 << std::endl;
+        std::cout << "features count: " << n << std::endl;
+    }
+    features.insert(features.end(), out.begin(), out.begin() + (long)n);
+}
+
+void run_detect(const std::vector<Mat> &dog_pyr, std::vector<Keypoint> &extrema, int octaves, int intervals, int ni)
+{
+    if (intervals != INTERVALS || octaves < 0 || dog_pyr.size() < (size_t)octaves * (INTERVALS + 2)) {
+        set_status(SG_E_INVALID, "DetectionLocalExtrema: bad pyramid");
+        return;
+    }
+    if (octaves == 0) {
+        set_status(SG_OK);
+        return;
+    }
+    const int rows = dog_pyr[0].rows, cols = dog_pyr[0].cols;
+    sg_ctx *ctx = context_for_plane(cols, rows);
+    if (!ctx)
+        return;
+    std::vector<PlaneView> views;
+    views.reserve((size_t)octaves * (INTERVALS + 2));
+    std::vector<const double *> ptrs;
+    for (int i = 0; i < octaves * (INTERVALS + 2); i++) {
+        if (!is_f64_plane(dog_pyr[i])) {
+            set_status(SG_E_INVALID, "DetectionLocalExtrema: levels must be CV_64FC1");
+            return;
+        }
+        views.emplace_back(dog_pyr[i]);
+        ptrs.push_back(views.back().p);
+    }
+    size_t cap = (size_t)rows * cols / 40 + 4096, n = 0;
+    std::vector<Keypoint> out(cap);
+    sg_counters c;
+    int rc = sg_detect_local_extrema(ctx, ptrs.data(), cols, rows, octaves, intervals, ni,
+                                     reinterpret_cast<sg_keypoint *>(out.data()), cap, &n, &c);
+    set_status(rc);
+    if (rc != SG_OK)
+        return;
+    if (tls.verbose)
+        std::cout << "cc00: " << c.cc00 << ", cc0: " << c.cc0 << ", cc1: " << c.cc1 << ", cc2: " << c.cc2
+                  << ", cc3: " << c.cc3 << std::endl;
+    extrema.insert(extrema.end(), out.begin(), out.begin() + (long)n);
+}
+
+bool gauss_ptrs(const std::vector<Mat> &gauss_pyr, int octaves, std::vector<PlaneView> &views,
+                std::vector<const double *> &ptrs)
+{
+    views.reserve((size_t)octaves * (INTERVALS + 3));
+    for (int i = 0; i < octaves * (INTERVALS + 3); i++) {
+        if (!is_f64_plane(gauss_pyr[i]))
+            return false;
+        views.emplace_back(gauss_pyr[i]);
+        ptrs.push_back(views.back().p);
+    }
+    return true;
+}
+
+} // namespace
+
+// ------------------------------------------------------------------------------------------ additions
+
+int SiftLastStatus() { return tls.status; }
+const char *SiftLastError() { return tls.error.c_str(); }
+void SiftSetDevice(int device)
+{
+    if (device != tls.device)
+        SiftReleaseContext();
+    tls.device = device;
+}
+void SiftSetVerbose(bool on) { tls.verbose = on; }
+void SiftReleaseContext()
+{
+    if (tls.ctx)
+        sg_destroy(tls.ctx);
+    tls.ctx = nullptr;
+    tls.max_w = tls.max_h = 0;
+}
+
+// ------------------------------------------------------------------------------------------ stages
+
+// sift/sift.cpp:20-51; dst is created only when empty, like the reference
+void ConvertToGray(const Mat &src, Mat &dst)
+{
+    if (src.empty() || src.depth() != CV_8U || src.channels() < 3) {
+        set_status(SG_E_INVALID, "ConvertToGray needs an 8-bit image with at least 3 channels");
+        return;
+    }
+    if (dst.empty())
+        dst.create(src.rows, src.cols, CV_64FC1);
+    if (dst.rows != src.rows || dst.cols != src.cols || dst.type() != CV_64FC1 || !dst.isContinuous()) {
+        set_status(SG_E_INVALID, "ConvertToGray: dst has the wrong shape");
+        return;
+    }
+    sg_ctx *ctx = context_for_plane(src.cols, src.rows);
+    if (!ctx)
+        return;
+    set_status(sg_convert_to_gray(ctx, src.data, src.cols, src.rows, src.channels(), src.step,
+                                  reinterpret_cast<double *>(dst.data)));
+}
+
+// sift/sift.cpp:59-103
+void DownSample(const Mat &src, Mat &dst)
+{
+    if (src.empty() || src.channels() != 1 || src.type() != CV_64FC1)
+        return;
+    if (src.cols <= 1 || src.rows <= 1) {
+        src.copyTo(dst);
+        return;
+    }
+    dst.create(src.rows / 2, src.cols / 2, CV_64FC1);
+    sg_ctx *ctx = context_for_plane(src.cols, src.rows);
+    if (!ctx)
+        return;
+    PlaneView v(src);
+    set_status(sg_downsample(ctx, v.p, src.cols, src.rows, reinterpret_cast<double *>(dst.data)));
+}
+
+// sift/sift.cpp:111-175
+void UpSample(const Mat &src, Mat &dst)
+{
+    if (src.empty() || src.channels() != 1 || src.type() != CV_64FC1)
+        return;
+    dst.create(src.rows * 2, src.cols * 2, CV_64FC1);
+    if (src.rows < 2 || src.cols < 2) { // the reference leaves such a dst unwritten; keep it defined
+        std::memset(dst.data, 0, (size_t)(dst.dataend - dst.data));
+        return;
+    }
+    sg_ctx *ctx = context_for_plane(2 * src.cols, 2 * src.rows);
+    if (!ctx)
+        return;
+    PlaneView v(src);
+    set_status(sg_upsample(ctx, v.p, src.cols, src.rows, reinterpret_cast<double *>(dst.data)));
+}
+
+// sift/sift.cpp:323-326
+void GaussianSmooth(const Mat &src, Mat &dst, double sigma)
+{
+    if (!is_f64_plane(src) || !(sigma > 0)) {
+        set_status(SG_E_INVALID, "GaussianSmooth needs a CV_64FC1 image and sigma > 0");
+        return;
+    }
+    sg_ctx *ctx = context_for_plane(src.cols, src.rows);
+    if (!ctx)
+        return;
+    PlaneView v(src); // taken before dst.create so that in-place calls (src and dst the same Mat) work
+    Mat out(src.rows, src.cols, CV_64FC1);
+    int rc = sg_gaussian_smooth(ctx, v.p, reinterpret_cast<double *>(out.data), src.cols, src.rows, sigma);
+    set_status(rc);
+    if (rc == SG_OK)
+        dst = out;
+}
+
+// sift/sift.cpp:335-346
+void CreateInitSmoothGray(const Mat &src, Mat &dst, double sigma)
+{
+    if (src.empty() || src.depth() != CV_8U || src.channels() < 3 || src.rows < 2 || src.cols < 2) {
+        set_status(SG_E_INVALID, "CreateInitSmoothGray needs an 8-bit image with at least 3 channels");
+        return;
+    }
+    sg_ctx *ctx = context_for(src.cols, src.rows, tls.ctx ? tls.sigma : SIGMA, tls.ctx ? tls.nointerval : 0);
+    if (!ctx)
+        return;
+    Mat out(2 * src.rows, 2 * src.cols, CV_64FC1);
+    int rc = sg_create_init_smooth_gray(ctx, src.data, src.cols, src.rows, src.channels(), src.step, sigma,
+                                        reinterpret_cast<double *>(out.data));
+    set_status(rc);
+    if (rc == SG_OK)
+        dst = out;
+}
+
+// sift/sift.cpp:357-407; appends octaves*(intervals+3) levels
+void GaussianPyramid(const Mat &src, std::vector<Mat> &gauss_pyr, int octaves, int intervals, double sigma)
+{
+    if (!is_f64_plane(src) || octaves < 0 || intervals != INTERVALS) {
+        set_status(SG_E_INVALID, "GaussianPyramid needs a CV_64FC1 base and intervals == 3");
+        return;
+    }
+    sg_ctx *ctx = context_for_plane(src.cols, src.rows);
+    if (!ctx)
+        return;
+    std::vector<int> r, c;
+    octave_dims(src.rows, src.cols, octaves, r, c);
+    std::vector<Mat> levels;
+    std::vector<double *> ptrs;
+    for (int o = 0; o < octaves; o++)
+        for (int i = 0; i < intervals + 3; i++) {
+            levels.emplace_back(r[o], c[o], CV_64FC1);
+            ptrs.push_back(reinterpret_cast<double *>(levels.back().data));
+        }
+    PlaneView v(src);
+    int rc = sg_gaussian_pyramid(ctx, v.p, src.cols, src.rows, octaves, intervals, sigma, ptrs.data());
+    set_status(rc);
+    if (rc == SG_OK)
+        gauss_pyr.insert(gauss_pyr.end(), levels.begin(), levels.end());
+}
+
+// sift/sift.cpp:416-437; like the reference, returns silently on a shape mismatch or a non-empty c
+void Sub(const Mat &a, const Mat &b, Mat &c)
+{
+    if (a.rows != b.rows || a.cols != b.cols || a.type() != b.type())
+        return;
+    if (!c.empty())
+        return;
+    if (!is_f64_plane(a)) {
+        set_status(SG_E_INVALID, "Sub needs CV_64FC1 images");
+        return;
+    }
+    sg_ctx *ctx = context_for_plane(a.cols, a.rows);
+    if (!ctx)
+        return;
+    c.create(a.rows, a.cols, CV_64FC1);
+    PlaneView va(a), vb(b);
+    set_status(sg_sub(ctx, va.p, vb.p, reinterpret_cast<double *>(c.data), a.cols, a.rows));
+}
+
+// sift/sift.cpp:447-461; appends octaves*(intervals+2) levels
+void DogPyramid(const std::vector<Mat> &gauss_pyr, std::vector<Mat> &dog_pyr, int octaves, int intervals)
+{
+    if (intervals != INTERVALS || octaves < 0 || gauss_pyr.size() < (size_t)octaves * (INTERVALS + 3)) {
+        set_status(SG_E_INVALID, "DogPyramid: bad pyramid");
+        return;
+    }
+    for (int o = 0; o < octaves; o++)
+        for (int i = 1; i < intervals + 3; i++) {
+            Mat m;
+            Sub(gauss_pyr[o * (intervals + 3) + i], gauss_pyr[o * (intervals + 3) + i - 1], m);
+            if (tls.status != SG_OK)
+                return;
+            dog_pyr.push_back(m);
+        }
+}
+
+// sift/sift.cpp:920-987 and 989-1056
+void DetectionLocalExtrema(const std::vector<Mat> &dog_pyr, std::vector<Keypoint> &extrema, int octaves, int intervals)
+{
+    run_detect(dog_pyr, extrema, octaves, intervals, 0);
+}
+
+void DetectionLocalExtrema_nointerval(const std::vector<Mat> &dog_pyr, std::vector<Keypoint> &extrema, int octaves,
+                                      int intervals)
+{
+    run_detect(dog_pyr, extrema, octaves, intervals, 1);
+}
+
+// sift/sift.cpp:1065-1077
+void CalculateScale(std::vector<Keypoint> &features, double sigma, int intervals)
+{
+    set_status(sg_calculate_scale(reinterpret_cast<sg_keypoint *>(features.data()), features.size(), sigma, intervals));
+}
+
+// sift/sift.cpp:1085-1096
+void HalfFeatures(std::vector<Keypoint> &features)
+{
+    set_status(sg_half_features(reinterpret_cast<sg_keypoint *>(features.data()), features.size()));
+}
+
+// sift/sift.cpp:1317-1339; appends one record per orientation peak
+void OrientationAssignment(std::vector<Keypoint> &extrema, std::vector<Keypoint> &features,
+                           const std::vector<Mat> &gauss_pyr)
+{
+    const int octaves = (int)(gauss_pyr.size() / (INTERVALS + 3));
+    if (octaves == 0 || extrema.empty()) {
+        set_status(SG_OK);
+        return;
+    }
+    sg_ctx *ctx = context_for_plane(gauss_pyr[0].cols, gauss_pyr[0].rows);
+    if (!ctx)
+        return;
+    std::vector<PlaneView> views;
+    std::vector<const double *> ptrs;
+    if (!gauss_ptrs(gauss_pyr, octaves, views, ptrs)) {
+        set_status(SG_E_INVALID, "OrientationAssignment: levels must be CV_64FC1");
+        return;
+    }
+    size_t cap = 2 * extrema.size() + 64, n = 0;
+    std::vector<Keypoint> out(cap);
+    int rc = sg_orientation_assignment(ctx, reinterpret_cast<const sg_keypoint *>(extrema.data()), extrema.size(),
+                                       ptrs.data(), gauss_pyr[0].cols, gauss_pyr[0].rows, octaves,
+                                       reinterpret_cast<sg_keypoint *>(out.data()), cap, &n);
+    if (rc == SG_E_CAPACITY && n > cap) {
+        cap = n;
+        out.resize(cap);
+        rc = sg_orientation_assignment(ctx, reinterpret_cast<const sg_keypoint *>(extrema.data()), extrema.size(),
+                                       ptrs.data(), gauss_pyr[0].cols, gauss_pyr[0].rows, octaves,
+                                       reinterpret_cast<sg_keypoint *>(out.data()), cap, &n);
+    }
+    set_status(rc);
+    if (rc == SG_OK)
+        features.insert(features.end(), out.begin(), out.begin() + (long)n);
+}
+
+// sift/sift.cpp:1607-1631
+void DescriptorRepresentation(std::vector<Keypoint> &features, const std::vector<Mat> &gauss_pyr, int bins, int width)
+{
+    if (bins != DESCR_HIST_BINS || width != DESCR_WINDOW_WIDTH) {
+        set_status(SG_E_UNSUPPORTED, "DescriptorRepresentation supports the 4x4x8 layout only");
+        return;
+    }
+    const int octaves = (int)(gauss_pyr.size() / (INTERVALS + 3));
+    if (octaves == 0 || features.empty()) {
+        set_status(SG_OK);
+        return;
+    }
+    sg_ctx *ctx = context_for_plane(gauss_pyr[0].cols, gauss_pyr[0].rows);
+    if (!ctx)
+        return;
+    std::vector<PlaneView> views;
+    std::vector<const double *> ptrs;
+    if (!gauss_ptrs(gauss_pyr, octaves, views, ptrs)) {
+        set_status(SG_E_INVALID, "DescriptorRepresentation: levels must be CV_64FC1");
+        return;
+    }
+    set_status(sg_descriptor_representation(ctx, reinterpret_cast<sg_keypoint *>(features.data()), features.size(),
+                                            ptrs.data(), gauss_pyr[0].cols, gauss_pyr[0].rows, octaves));
+}
+
+// sift/sift.cpp:1640-1643
+bool FeatureCmp(Keypoint &f1, Keypoint &f2) { return f1.scale < f2.scale; }
+
+// ------------------------------------------------------------------------------------------ drivers
+
+// sift/sift.cpp:1646-1707
+void Sift(const Mat &src, std::vector<Keypoint> &features, double sigma, int intervals)
+{
+    run_sift(src, features, sigma, intervals, 0);
+}
+
+// sift/sift.cpp:1709-1770
+void Sift_nointerval(const Mat &src, std::vector<Keypoint> &features, double sigma, int intervals)
+{
+    run_sift(src, features, sigma, intervals, 1);
+}
+
+// ------------------------------------------------------------------------------------------ text files
+
+// sift/sift.cpp:1886-1908: "n dims", then per feature "dy dx scale ori" and dims descriptor values
+void read_features(std::vector<Keypoint> &features, const char *file)
+{
+    std::ifstream in(file);
+    int n = 0, dims = 0;
+    in >> n >> dims;
+    if (!in || dims < 0 || dims > FEATURE_ELEMENT_LENGTH) {
+        set_status(SG_E_INVALID, "read_features: bad header");
+        return;
+    }
+    for (int i = 0; i < n; i++) {
+        Keypoint key;
+        std::memset(&key, 0, sizeof key);
+        in >> key.dy >> key.dx >> key.scale >> key.ori;
+        for (int j = 0; j < dims; j++)
+            in >> key.descriptor[j];
+        if (!in) {
+            set_status(SG_E_INVALID, "read_features: truncated file");
+            return;
+        }
+        key.descr_length = dims;
+        features.push_back(key);
+    }
+    set_status(SG_OK);
+}
+
+// sift/sift.cpp:1910-1931: default stream formatting, a line break before every 20th descriptor value
+void write_features(const std::vector<Keypoint> &features, const char *file)
+{
+    std::ofstream out(file);
+    out << features.size() << " " << FEATURE_ELEMENT_LENGTH << std::endl;
+    for (size_t i = 0; i < features.size(); i++) {
+        const Keypoint &f = features[i];
+        out << f.dy << " " << f.dx << " " << f.scale << " " << f.ori << std::endl;
+        for (int j = 0; j < FEATURE_ELEMENT_LENGTH; j++) {
+            if (j % 20 == 0)
+                out << std::endl;
+            out << f.descriptor[j] << " ";
+        }
+        out << std::endl << std::endl;
+    }
+    set_status(out ? SG_OK : SG_E_INVALID, out ? nullptr : "write_features: cannot write file");
+}

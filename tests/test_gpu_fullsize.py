@@ -1,0 +1,98 @@
+"""Full-size configurations: known answers recorded from the reference's pipeline on the same seeded inputs,
+the oracle beside the HIP path at 1080p, and size-independent properties where the oracle is too slow."""
+import numpy as np
+import pytest
+
+from sift_amd.parity import descriptor_agreement, match_features
+
+pytestmark = pytest.mark.gpu
+
+# vnoise5 inputs; (cc00, cc0, cc1, cc2, cc3), features, keypoints per octave -- recorded from the reference's own run
+KNOWN_1080P_S1234 = ((32820570, 11196758, 40757, 18437, 18276), 21955, [7090, 8269, 2240, 534, 131, 8, 4, 0, 0])
+KNOWN_1080P_S7 = (18386, 22151, [7092, 8408, 2228, 536, 105, 17, 0, 0, 0])
+KNOWN_8K_S1234 = (298170, 360706, [115219, 135575, 36559, 8562, 1930, 300, 24, 1, 0, 0, 0])
+
+
+@pytest.fixture(scope="module")
+def ctx1080():
+    import sift_amd
+    c = sift_amd.SiftGPU(max_width=1920, max_height=1080, max_batch=2)
+    yield c
+    c.close()
+
+
+def _per_octave(kp, octaves):
+    return np.bincount(kp["octave"], minlength=octaves).tolist()
+
+
+def test_1080p_known_answers_and_oracle(oracle, ctx1080):
+    import sift_amd
+    img = sift_amd.vnoise5(1920, 1080, 1234)
+    got = ctx1080.extract(img)
+    counters, n_feat, per_oct = KNOWN_1080P_S1234
+    assert ctx1080.read_counters() == counters
+    assert len(got) == n_feat
+    assert _per_octave(ctx1080.read_keypoints(), 9) == per_oct
+    assert (np.diff(got["scale"]) >= 0).all()
+    # the oracle on the same image (about 7 s of CPU)
+    ref, nk, ctr, _ = oracle.sift(img)
+    assert ctr == counters and len(ref) == n_feat
+    for f in ("x", "y", "octave", "interval"):
+        assert np.array_equal(got[f], ref[f]), f
+    assert np.array_equal(got["descriptor"], ref["descriptor"])
+    pairs = match_features(ref, got)
+    assert len(pairs) == len(ref)  # every feature within 0.5 px, 1 % scale, 1 degree
+    assert descriptor_agreement(ref["descriptor"][pairs[:, 0]], got["descriptor"][pairs[:, 1]]) == (1.0, 1.0, 0.0)
+
+
+def test_1080p_second_seed_counts(ctx1080):
+    import sift_amd
+    got = ctx1080.extract(sift_amd.vnoise5(1920, 1080, 7))
+    n_kp, n_feat, per_oct = KNOWN_1080P_S7
+    assert len(got) == n_feat
+    kp = ctx1080.read_keypoints()
+    assert len(kp) == n_kp and _per_octave(kp, 9) == per_oct
+
+
+def test_1080p_batch_is_deterministic_and_equals_single(ctx1080):
+    import sift_amd
+    imgs = np.stack([sift_amd.vnoise5(1920, 1080, 1000 + i) for i in range(2)])
+    a = ctx1080.extract_batch(imgs, 32768)
+    b = ctx1080.extract_batch(imgs, 32768)
+    for i in range(2):
+        assert a[i].tobytes() == b[i].tobytes()
+        single = ctx1080.extract(imgs[i])
+        assert len(single) == len(a[i])
+        assert np.array_equal(single["descriptor"].astype(np.uint8), a[i]["desc"])
+        assert (np.diff(a[i]["scale"]) >= 0).all()
+
+
+def test_8k_image_known_counts():
+    """7680x4320 with the upsampled base octave (11 octaves, 15360x8640 base): counts recorded from the reference."""
+    import sift_amd
+    n_kp, n_feat, per_oct = KNOWN_8K_S1234
+    with sift_amd.SiftGPU(max_width=7680, max_height=4320) as ctx:
+        d_img = ctx.malloc(7680 * 4320 * 3)
+        cap = 400000
+        d_out = ctx.malloc(cap * 144)
+        d_cnt = ctx.malloc(4)
+        try:
+            ctx.synth_vnoise5(d_img, 7680, 4320, 1234)
+            ctx.extract_batch_device(d_img, 1, 7680, 4320, 3, d_out, cap, d_cnt)
+            ctx.sync()
+            cnt = np.zeros(1, dtype=np.uint32)
+            ctx.d2h(cnt, d_cnt)
+            out = np.zeros(cap, dtype=sift_amd.PACKED_DTYPE)
+            ctx.d2h(out, d_out)
+        finally:
+            ctx.free(d_img)
+            ctx.free(d_out)
+            ctx.free(d_cnt)
+        assert ctx.last_octaves() == 11
+        assert int(cnt[0]) == n_feat
+        kp = ctx.read_keypoints()
+        assert len(kp) == n_kp and _per_octave(kp, 11) == per_oct
+        f = out[:n_feat]
+        assert (np.diff(f["scale"]) >= 0).all()
+        assert f["x"].min() >= 0 and f["x"].max() < 7680 and f["y"].min() >= 0 and f["y"].max() < 4320
+        assert f["desc"].max() <= 255 and f["desc"].any(axis=1).all()

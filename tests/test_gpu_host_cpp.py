@@ -1,0 +1,43 @@
+"""The host C++ layer (the reference's sift.h entry points over the C ABI), exercised as compiled programs."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "sift_amd", "host")
+
+
+def _need(exe):
+    path = os.path.join(HOST, exe)
+    if not os.path.exists(path):
+        pytest.fail("%s is not built (run __graft_entry__.build())" % path)
+    return path
+
+
+def test_demo_flow_matches_oracle_text(oracle, tmp_path):
+    """Sift() and Sift_nointerval() + write_features, as in the reference's main(): the text files equal the
+    ones the CPU oracle writes for the same images."""
+    exe = _need("sift_demo")
+    w, h, s1, s2 = 200, 150, 1234, 4321
+    o1, o2 = str(tmp_path / "d1.txt"), str(tmp_path / "d2.txt")
+    out = subprocess.run([exe, str(w), str(h), str(s1), str(s2), o1, o2], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    f1, _, _, _ = oracle.sift(oracle.vnoise5(w, h, s1))
+    f2, _, _, _ = oracle.sift(oracle.vnoise5(w, h, s2), nointerval=True)
+    r1, r2 = str(tmp_path / "r1.txt"), str(tmp_path / "r2.txt")
+    oracle.write_features(f1, r1)
+    oracle.write_features(f2, r2)
+    assert open(o1, "rb").read() == open(r1, "rb").read()
+    assert open(o2, "rb").read() == open(r2, "rb").read()
+    assert "features1 %d features2 %d" % (len(f1), len(f2)) in out.stdout
+
+
+def test_stage_entry_points_equal_driver():
+    exe = _need("sift_stage_chain")
+    out = subprocess.run([exe, "160", "120", "77"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "stage chain ok" in out.stdout

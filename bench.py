@@ -54,7 +54,9 @@ def main():
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64")
     ap.add_argument("--pool", type=int, default=256, help="distinct frames kept resident per GPU")
     ap.add_argument("--cap", type=int, default=32768, help="packed-feature capacity per frame")
-    ap.add_argument("--contexts", type=int, default=2, help="batches in flight per GPU")
+    ap.add_argument("--contexts", type=int, default=1,
+                    help="batches in flight per GPU (1: per-kernel event times are undisturbed; 2 overlaps\n"
+                         "memory-bound and compute-bound kernels of consecutive batches for a few % more throughput)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = box share)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-launch HIP events")
@@ -190,37 +192,54 @@ def main():
     N0 = float(px[0]) if px else 0.0
     taps = [11, 11, 13, 17, 21, 27]
     radius_name = {0: 5, 1: 5, 2: 6, 3: 8, 4: 10, 5: 13}
-    # algorithmic bytes of one blur pass over one frame: every pixel read once and written once
+    tname = "double" if esize == 8 else "float"
+    fused = not any(stage_ms.get("blur_row%d" % l, 0.0) > 0 for l in range(6))
+    # Algorithmic bytes of one blur launch: every pixel of the level read once and written once
+    # (2 * sizeof(T) per pixel) -- per launch of the fused kernel, or per pass of the two-pass kernels.
     blur = {}
     tot_bytes = tot_ms = 0.0
-    for kind in ("row", "col"):
+    for kind in (("col",) if fused else ("row", "col")):
         for lvl in range(6):
             key = "blur_%s%d" % (kind, lvl)
             ms, ln = stage_ms.get(key, 0.0), stage_launches.get(key, 0)
             per_frame_px = N0 if lvl == 0 else P
             nbytes = 2.0 * esize * per_frame_px * B * K
             if ms > 0:
-                blur[key] = {"taps": taps[lvl], "launches": int(ln), "avg_us": 1e3 * ms / max(ln, 1),
-                             "GBps": nbytes / (ms * 1e-3) / 1e9}
+                kname = ("blur_fused_k<%s,R=%d>" % (tname, radius_name[lvl])) if fused else \
+                    ("blur_%s_k<%s,R=%d>" % (kind, tname, radius_name[lvl]))
+                blur[key] = {"kernel": kname, "taps": taps[lvl], "launches": int(ln), "avg_us": 1e3 * ms / max(ln, 1),
+                             "GBps": nbytes / (ms * 1e-3) / 1e9, "bytes_per_launch_avg": nbytes / max(ln, 1)}
                 tot_bytes += nbytes
                 tot_ms += ms
-    dom_key = max(blur, key=lambda k: blur[k]["avg_us"] * blur[k]["launches"]) if blur else None
+    # the kernel name the profiler reports merges stage slots that share a template instantiation (R=5: slots 0, 1)
+    by_kernel = {}
+    for key, d in blur.items():
+        e = by_kernel.setdefault(d["kernel"], {"ms": 0.0, "launches": 0, "bytes": 0.0, "taps": d["taps"]})
+        e["ms"] += d["avg_us"] * d["launches"] * 1e-3
+        e["launches"] += d["launches"]
+        e["bytes"] += d["bytes_per_launch_avg"] * d["launches"]
     roofline = None
-    if dom_key:
-        d = blur[dom_key]
-        lvl = int(dom_key[-1])
-        per_frame_px = N0 if lvl == 0 else P
-        nbytes_launch = 2.0 * esize * per_frame_px * B * K / d["launches"]
+    if by_kernel:
+        dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
+        e = by_kernel[dom]
+        gbps = e["bytes"] / (e["ms"] * 1e-3) / 1e9
         roofline = {
             "bound": "hbm",
-            "kernel": "blur_%s_k<%s,R=%d> (%d-tap %s pass, average over the octaves' launches)" % (
-                dom_key[5:8], "double" if esize == 8 else "float", radius_name[lvl], taps[lvl],
-                "row" if "row" in dom_key else "column"),
-            "achieved": d["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": d["GBps"] / HBM_PEAK_GBPS,
+            "kernel": dom + (" (row + column pass of a %d-tap Gaussian in one launch; all octaves' launches)" % e["taps"]
+                             if fused else " (%d-tap pass; all octaves' launches)" % e["taps"]),
+            "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
             "traffic": None,
-            "launches": d["launches"], "avg_launch_us": d["avg_us"], "algorithmic_bytes_per_launch": nbytes_launch,
-            "all_blur_passes_GBps": (tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else None,
+            "launches": e["launches"], "avg_launch_us": 1e3 * e["ms"] / e["launches"],
+            "algorithmic_bytes_per_launch": e["bytes"] / e["launches"],
+            "all_blur_launches_GBps": (tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else None,
         }
+    det_ms = stage_ms.get("detect", 0.0)
+    detect = None
+    if det_ms > 0:
+        det_bytes = 6.0 * esize * P * B * K  # the six Gaussian levels of every octave, read once
+        detect = {"kernel": "detect_k<%s> (fused DoG + 3x3x3 extrema scan; per-octave launches)" % tname,
+                  "launches": int(stage_launches.get("detect", 0)), "GBps": det_bytes / (det_ms * 1e-3) / 1e9,
+                  "frac": det_bytes / (det_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1:
@@ -250,7 +269,7 @@ def main():
         "images_per_sec_per_gpu": value / world,
         "roofline": roofline, "cpu_baseline": cpu_baseline,
         "stage_ms_per_step": {k: v / K for k, v in stage_ms.items() if v > 0},
-        "blur_kernels": blur,
+        "blur_kernels": blur, "detect_kernel": detect,
     }
     print(json.dumps(line))
     if world > 1:

@@ -39,6 +39,11 @@ __device__ __forceinline__ void lds_add(double *p, double v)
 // [1/4 1/2 1/4] filter (sift.cpp:1209-1221), the maximum (sift.cpp:1231-1240) and the peak test with
 // parabolic refinement (sift.cpp:1280-1307) run on lanes 0..35.
 constexpr int kOriCopies = 4;
+constexpr int kOriPatch = 35; // window side + rim for radius <= 16 (the default parameters' maximum)
+
+// Same-wave LDS hand-off: LDS operations of one wave complete in order, so waiting for the wave's own
+// outstanding LDS operations makes earlier stores and atomics visible to its later loads (other lanes included).
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 template <typename T>
 __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, size_t kp_img,
@@ -49,7 +54,9 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
 {
     __shared__ double hist[4][kOriCopies][64];
     __shared__ double etab[4][64];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double patch_s[4][kOriPatch * kOriPatch];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    double *patch = patch_s[wave];
     double *hs = hist[wave][0];
     double *hc = hist[wave][lane & (kOriCopies - 1)];
     double *E = etab[wave];
@@ -57,42 +64,93 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
     const unsigned int n = min(kp_count[b], cap);
     const double PI2 = 2.0 * SG_PI;
 
-    for (unsigned int j0 = blockIdx.x * 4u; j0 < n; j0 += gridDim.x * 4u) {
-        const unsigned int j = j0 + wave;
-        const bool active = j < n;
-        KpRec r;
-        int radius = 0;
-        double econs = 0.0;
+    // every wave walks its own keypoints; nothing is shared between the waves of a block.  The slot index two
+    // keypoints ahead and the record one keypoint ahead are loaded while the current keypoint is processed.
+    const unsigned int jstep = gridDim.x * 4u;
+    const unsigned int j_first = blockIdx.x * 4u + wave;
+    const unsigned int *ks = kp_src + (size_t)b * src_img;
+    const KpRec *kpb = kp + (size_t)b * kp_img;
+    KpRec rec_next;
+    unsigned int slot_next2 = 0;
+    if (j_first < n)
+        rec_next = kpb[ks[j_first]];
+    if (j_first + jstep < n)
+        slot_next2 = ks[j_first + jstep];
+    for (unsigned int j = j_first; j < n; j += jstep) {
+        const KpRec r = rec_next;
+        if (j + jstep < n)
+            rec_next = kpb[slot_next2];
+        if (j + 2 * jstep < n)
+            slot_next2 = ks[j + 2 * jstep];
+        const int radius = (int)rint(3.0 * 1.5 * r.oscale); // ORI_WINDOW_RADIUS * octave_scale
+        const double sig = 1.5 * r.oscale;                   // ORI_SIGMA_TIMES * octave_scale
+        const double econs = -1.0 / (2.0 * sig * sig);
 #pragma unroll
         for (int q = 0; q < kOriCopies; q++)
             hist[wave][q][lane] = 0.0;
-        if (active) {
-            r = kp[(size_t)b * kp_img + kp_src[(size_t)b * src_img + j]];
-            radius = (int)rint(3.0 * 1.5 * r.oscale); // ORI_WINDOW_RADIUS * octave_scale
-            const double sig = 1.5 * r.oscale;        // ORI_SIGMA_TIMES * octave_scale
-            econs = -1.0 / (2.0 * sig * sig);
-            E[lane] = exp((lane * lane) * econs);
-        }
-        __syncthreads();
-        if (active) {
+        E[lane] = exp((lane * lane) * econs);
+        wave_lds_fence();
+        {
             const int o = r.octave;
             const T *g = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o];
             const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
             const int W = 2 * radius + 1, total = W * W;
             const bool use_tab = radius < 64;
+            // The window plus a one-pixel rim is staged in LDS first (all loads in flight at once, clamped at
+            // the image border; validity is still decided from the coordinates), unless it exceeds the patch.
+            const int S = W + 2;
+            const bool use_patch = S <= kOriPatch;
+            if (use_patch) {
+                const int px0 = r.x - radius - 1, py0 = r.y - radius - 1;
+                int ey = lane / S, ex = lane - ey * S;
+                const int edq = 64 / S, edr = 64 - edq * S;
+                for (int e = lane; e < S * S; e += 64) {
+                    int yy = min(max(py0 + ey, 0), rows - 1), xx = min(max(px0 + ex, 0), cols - 1);
+                    patch[e] = (double)g[(size_t)yy * pitch + xx];
+                    ey += edq;
+                    ex += edr;
+                    if (ex >= S) {
+                        ex -= S;
+                        ey++;
+                    }
+                }
+                wave_lds_fence();
+            }
             // sample s -> (i = s / W - radius: x offset, the reference's outer loop; jj = s % W - radius: y offset)
             int qi = lane / W, qj = lane - qi * W;
             const int dq = 64 / W, dr = 64 - dq * W;
-            for (int s = lane; s < total; s += 64) {
+#if SG_ABL == 11
+            double abl_o = 0;
+#endif
+            for (int s = lane; s < (SG_ABL == 13 ? 0 : total); s += 64) {
                 const int i = qi - radius, jj = qj - radius;
                 double dx, dy;
-                if (grad_at(g, rows, cols, pitch, r.x + i, r.y + jj, dx, dy)) {
+                bool ok;
+                if (use_patch) {
+                    const int x = r.x + i, y = r.y + jj;
+                    ok = x > 0 && x < cols - 1 && y > 0 && y < rows - 1;
+                    const double *pp = patch + (qj + 1) * S + (qi + 1);
+                    dx = pp[1] - pp[-1];
+                    dy = pp[S] - pp[-S];
+                } else {
+                    ok = grad_at(g, rows, cols, pitch, r.x + i, r.y + jj, dx, dy);
+                }
+                if (ok) {
+#if SG_ABL == 12
+                    double mag = dx * dx + dy * dy;
+                    double ori = dx * 3 + dy;
+#else
                     double mag = sg_sqrt(dx * dx + dy * dy);
                     double ori = sg_atan2(dy, dx);
+#endif
                     double weight = use_tab ? E[abs(i)] * E[abs(jj)] : exp((i * i + jj * jj) * econs);
                     int bin = (int)rint(kOriBins * (SG_PI - ori) / PI2);
                     bin = bin < kOriBins ? bin : 0;
+#if SG_ABL == 11
+                    abl_o += mag * weight + bin;
+#else
                     lds_add(&hc[bin], mag * weight);
+#endif
                 }
                 qi += dq;
                 qj += dr;
@@ -101,32 +159,40 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
                     qi++;
                 }
             }
+#if SG_ABL == 11
+            if (abl_o == 123.456) hs[0] = 1;
+#endif
         }
-        __syncthreads();
-        if (active && lane < kOriBins)
-            hs[lane] = ((hist[wave][0][lane] + hist[wave][1][lane]) + hist[wave][2][lane]) + hist[wave][3][lane];
-        __syncthreads();
+        wave_lds_fence();
+        const bool binlane = lane < kOriBins;
+        double h0 = 0.0;
+        if (binlane)
+            h0 = ((hist[wave][0][lane] + hist[wave][1][lane]) + hist[wave][2][lane]) + hist[wave][3][lane];
+        wave_lds_fence();
+        if (binlane)
+            hs[lane] = h0;
+        wave_lds_fence();
         double c = 0.0;
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) { // ORI_SMOOTH_TIMES
-            if (active && lane < kOriBins) {
+            if (binlane) {
                 double prev = hs[lane == 0 ? kOriBins - 1 : lane - 1];
                 double next = hs[lane + 1 >= kOriBins ? 0 : lane + 1];
                 c = 0.25 * prev + 0.5 * hs[lane] + 0.25 * next;
             }
-            __syncthreads();
-            if (active && lane < kOriBins)
+            wave_lds_fence();
+            if (binlane)
                 hs[lane] = c;
-            __syncthreads();
+            wave_lds_fence();
         }
-        double mx = (active && lane < kOriBins) ? c : -1.0;
+        double mx = binlane ? c : -1.0;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
             double t = __shfl_xor(mx, d);
             mx = t > mx ? t : mx;
         }
         bool peak = false;
-        if (active && lane < kOriBins) {
+        if (binlane) {
             double l = hs[lane == 0 ? kOriBins - 1 : lane - 1];
             double rr = hs[(lane + 1) % kOriBins];
             double thr = mx * 0.8; // ORI_PEAK_RATIO
@@ -138,12 +204,12 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
             }
         }
         unsigned long long m = __ballot(peak);
-        if (active && lane == 0) {
+        if (lane == 0) {
             peak_words[(size_t)b * pw_img + j] = m;
             if (m)
                 atomicAdd(&chunk_sums[(size_t)b * chunks_img + j / kChunkWords], (unsigned int)__popcll(m));
         }
-        __syncthreads();
+        wave_lds_fence(); // the histograms are cleared for the next keypoint
     }
 }
 
@@ -195,12 +261,9 @@ __device__ __forceinline__ double block_sum_128(double v, double *red, int tid)
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, size_t kp_img,
-                                               const unsigned int *kp_src, size_t src_img,
-                                               const unsigned int *feat_src, size_t fsrc_img,
-                                               const unsigned int *feat_count, const double *ori_tmp, size_t ori_img,
-                                               uint8_t *desc, size_t desc_img, double *prequant, size_t pq_img,
-                                               double *fscale, size_t fs_img, unsigned int cap)
+__global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const FeatRec *frec, size_t frec_img,
+                                               const unsigned int *feat_count, uint8_t *desc, size_t desc_img,
+                                               double *prequant, size_t pq_img, unsigned int cap)
 {
     __shared__ double hist[4 * kDescCopies][128];
     __shared__ double etab[kDescTab];
@@ -210,12 +273,17 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
     const int b = blockIdx.y;
     const unsigned int n = min(feat_count[b], cap);
     const double PI2 = SG_PI * 2;
+    const FeatRec *fr = frec + (size_t)b * frec_img;
 
+    // the next feature's record is loaded while the current one is processed
+    FeatRec nxt;
+    if (blockIdx.x < n)
+        nxt = fr[blockIdx.x];
     for (unsigned int f = blockIdx.x; f < n; f += gridDim.x) {
-        const unsigned int fs = feat_src[(size_t)b * fsrc_img + f];
-        const unsigned int j = fs >> 6, pbin = fs & 63;
-        const KpRec r = kp[(size_t)b * kp_img + kp_src[(size_t)b * src_img + j]];
-        const double ori = ori_tmp[(size_t)b * ori_img + (size_t)j * kOriBins + pbin];
+        const FeatRec r = nxt;
+        if (f + gridDim.x < n)
+            nxt = fr[f + gridDim.x];
+        const double ori = r.ori;
         const int o = r.octave;
         const T *g = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o];
         const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
@@ -225,7 +293,7 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
         for (int q = 0; q < 4 * kDescCopies * 128 / 256; q++)
             hflat[tid + 256 * q] = 0.0;
 
-        const double cos_ori = cos(ori), sin_ori = sin(ori);
+        const double cos_ori = r.cos_ori, sin_ori = r.sin_ori; // cos(ori), sin(ori) (sift.cpp:1474-1475)
         const double shw = 3 * r.oscale;                             // DESCR_SCALE_ADJUST * octave_scale
         const double inv_shw = 1.0 / shw;
         const int radius = (int)((shw * sqrt(2.0) * (4 + 1)) / 2.0); // truncating cast (sift.cpp:1488)
@@ -357,8 +425,6 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
             }
             desc[(size_t)b * desc_img + (size_t)f * 128 + tid] = (uint8_t)qv;
         }
-        if (tid == 0)
-            fscale[(size_t)b * fs_img + f] = r.scale;
 #if SG_ABL == 1
         if (abl_acc == 123.456) desc[0] = 1;
 #endif
@@ -366,24 +432,61 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const KpRec *kp, s
     }
 }
 
-void launch_descr(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
-                  size_t src_img_stride, const unsigned int *feat_src, size_t fsrc_img_stride,
-                  const unsigned int *feat_count, const double *ori_tmp, size_t ori_img_stride, uint8_t *desc,
-                  size_t desc_img_stride, double *prequant, size_t pq_img_stride, double *fscale,
-                  size_t fs_img_stride, unsigned int cap, int B, int prec, hipStream_t s)
+void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_stride, const unsigned int *feat_count,
+                  uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
+                  int B, int prec, hipStream_t s)
 {
     unsigned int blocks = cap < 4096 ? cap : 4096;
     if (blocks == 0)
         return;
     dim3 g(blocks, B);
     if (prec == SG_F64)
-        descr_k<double><<<g, 256, 0, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, feat_src, fsrc_img_stride,
-                                          feat_count, ori_tmp, ori_img_stride, desc, desc_img_stride, prequant,
-                                          pq_img_stride, fscale, fs_img_stride, cap);
+        descr_k<double><<<g, 256, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,
+                                          pq_img_stride, cap);
     else
-        descr_k<float><<<g, 256, 0, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, feat_src, fsrc_img_stride,
-                                         feat_count, ori_tmp, ori_img_stride, desc, desc_img_stride, prequant,
-                                         pq_img_stride, fscale, fs_img_stride, cap);
+        descr_k<float><<<g, 256, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,
+                                         pq_img_stride, cap);
+}
+
+// One thread per feature: follows feat_src -> kp_src -> kp / ori_tmp once and leaves a compact record.
+__global__ __launch_bounds__(256) void feat_gather_k(const KpRec *kp, size_t kp_img, const unsigned int *kp_src,
+                                                     size_t src_img, const unsigned int *feat_src, size_t fsrc_img,
+                                                     const unsigned int *feat_count, const double *ori_tmp,
+                                                     size_t ori_img, FeatRec *frec, size_t frec_img, double *fscale,
+                                                     size_t fs_img, unsigned int cap)
+{
+    const int b = blockIdx.y;
+    const unsigned int n = min(feat_count[b], cap);
+    for (unsigned int f = blockIdx.x * 256u + threadIdx.x; f < n; f += gridDim.x * 256u) {
+        const unsigned int fs = feat_src[(size_t)b * fsrc_img + f];
+        const unsigned int j = fs >> 6, pbin = fs & 63;
+        const unsigned int slot = kp_src[(size_t)b * src_img + j];
+        const KpRec r = kp[(size_t)b * kp_img + slot];
+        FeatRec o;
+        o.x = r.x; o.y = r.y; o.octave = r.octave; o.interval = r.interval;
+        o.oscale = r.oscale; o.scale = r.scale;
+        o.ori = ori_tmp[(size_t)b * ori_img + (size_t)j * kOriBins + pbin];
+        o.cos_ori = cos(o.ori);
+        o.sin_ori = sin(o.ori);
+        o.kp_slot = slot; o.pad = 0;
+        frec[(size_t)b * frec_img + f] = o;
+        fscale[(size_t)b * fs_img + f] = r.scale;
+    }
+}
+
+void launch_feat_gather(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src, size_t src_img_stride,
+                        const unsigned int *feat_src, size_t fsrc_img_stride, const unsigned int *feat_count,
+                        const double *ori_tmp, size_t ori_img_stride, FeatRec *frec, size_t frec_img_stride,
+                        double *fscale, size_t fs_img_stride, unsigned int cap, int B, hipStream_t s)
+{
+    if (cap == 0)
+        return;
+    unsigned int blocks = (cap + 255) / 256;
+    if (blocks > 512)
+        blocks = 512;
+    dim3 g(blocks, B);
+    feat_gather_k<<<g, 256, 0, s>>>(kp, kp_img_stride, kp_src, src_img_stride, feat_src, fsrc_img_stride, feat_count,
+                                    ori_tmp, ori_img_stride, frec, frec_img_stride, fscale, fs_img_stride, cap);
 }
 
 // ---- ordering: stable rank by scale -----------------------------------------------------------------------

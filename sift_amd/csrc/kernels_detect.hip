@@ -20,6 +20,12 @@ struct DogAt {
     }
 };
 
+// max / min of finite pyramid differences
+__device__ __forceinline__ double vmax(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ double vmin(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
+__device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
+
 // ---- fused DoG + extrema scan ----------------------------------------------------------------------
 // One wave owns a 64-pixel segment of RS consecutive rows and all three scanned layers.  Each lane
 // keeps, for the 5 DoG levels, a 3-row x 3-column window in registers and slides it down the rows.
@@ -89,8 +95,8 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
             for (int r = 0; r < 3; r++) {
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
-                    a = d[r][l][c] > a ? d[r][l][c] : a;
-                    i = d[r][l][c] < i ? d[r][l][c] : i;
+                    a = vmax(a, d[r][l][c]);
+                    i = vmin(i, d[r][l][c]);
                 }
             }
             mx[l] = a; mn[l] = i;
@@ -102,10 +108,8 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
             bool pre = x_ok && (fabs((double)val) > thresh);
             T hi = mx[layer], lo = mn[layer];
             if (!NOINT) {
-                hi = mx[layer - 1] > hi ? mx[layer - 1] : hi;
-                hi = mx[layer + 1] > hi ? mx[layer + 1] : hi;
-                lo = mn[layer - 1] < lo ? mn[layer - 1] : lo;
-                lo = mn[layer + 1] < lo ? mn[layer + 1] : lo;
+                hi = vmax(vmax(hi, mx[layer - 1]), mx[layer + 1]);
+                lo = vmin(vmin(lo, mn[layer - 1]), mn[layer + 1]);
             }
             bool ext = pre && (val > (T)0 ? !(val < hi) : !(val > lo));
             unsigned long long mpre = __ballot(pre);

@@ -50,6 +50,15 @@ struct KpRec {
     double dx, dy, scale, oscale, val;
 };
 
+// Per-feature inputs of the descriptor stage, gathered (and cos/sin of the orientation evaluated) once per
+// feature by one thread, so that the 256 threads of a descriptor workgroup need a single 64-byte load.
+struct FeatRec {
+    int x, y, octave, interval;
+    double oscale, ori, scale;
+    double cos_ori, sin_ori;
+    unsigned int kp_slot, pad;
+};
+
 // ---- image preparation -----------------------------------------------------------------
 void launch_gray(const uint8_t *src, int rows, int cols, int ch, size_t stride, size_t img_stride,
                  const Plane &dst, int B, int prec, hipStream_t s);
@@ -91,11 +100,14 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
                    size_t src_img_stride, const unsigned int *kp_count, double *ori_tmp, size_t ori_img_stride,
                    unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
                    size_t chunks_img_stride, unsigned int cap, int B, int prec, hipStream_t s);
-void launch_descr(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
-                  size_t src_img_stride, const unsigned int *feat_src, size_t fsrc_img_stride,
-                  const unsigned int *feat_count, const double *ori_tmp, size_t ori_img_stride, uint8_t *desc,
-                  size_t desc_img_stride, double *prequant, size_t pq_img_stride, double *fscale,
-                  size_t fs_img_stride, unsigned int cap, int B, int prec, hipStream_t s);
+// gathers FeatRec[f] (and fscale[f]) from feat_src -> kp_src -> kp / ori_tmp
+void launch_feat_gather(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src, size_t src_img_stride,
+                        const unsigned int *feat_src, size_t fsrc_img_stride, const unsigned int *feat_count,
+                        const double *ori_tmp, size_t ori_img_stride, FeatRec *frec, size_t frec_img_stride,
+                        double *fscale, size_t fs_img_stride, unsigned int cap, int B, hipStream_t s);
+void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_stride, const unsigned int *feat_count,
+                  uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
+                  int B, int prec, hipStream_t s);
 // bwork: [B][2][kRankBuckets] scratch, blist: [B][cap] scratch, scratch_totals: [B], overflow_dummy: [1]
 void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
                  size_t rank_img_stride, unsigned int *bwork, unsigned int *blist, unsigned int *scratch_totals,

@@ -22,6 +22,7 @@ using namespace sg;
 static_assert(sizeof(sg_keypoint) == 1120, "sg_keypoint must match the reference's Keypoint layout");
 static_assert(sizeof(sg_packed_feature) == 144, "packed feature is 144 bytes");
 static_assert(sizeof(KpRec) == 80, "KpRec is 80 bytes");
+static_assert(sizeof(FeatRec) == 64, "FeatRec is 64 bytes");
 
 namespace {
 
@@ -67,6 +68,7 @@ struct sg_ctx {
     unsigned int *d_cand = nullptr, *d_kpsrc = nullptr, *d_fsrc = nullptr, *d_rank = nullptr;
     unsigned int *d_bwork = nullptr, *d_blist = nullptr, *d_rtot = nullptr; // rank scratch
     KpRec *d_kp = nullptr;
+    FeatRec *d_frec = nullptr;
     double *d_ori = nullptr, *d_pq = nullptr, *d_fscale = nullptr;
     uint8_t *d_desc = nullptr;
     unsigned int *d_counts = nullptr; // [3][B]: candidates, keypoints, features
@@ -335,10 +337,12 @@ static void descr_phase(sg_ctx *c, const OctaveTab &tab, int B)
     hipStream_t s = c->stream;
     unsigned int *n_feat = c->d_counts + 2 * c->B;
     {
-        StageScope sc(c, SG_ST_DESCR);
-        launch_descr(tab, c->d_kp, c->cand_cap, c->d_kpsrc, c->feat_cap, c->d_fsrc, c->feat_cap, n_feat, c->d_ori,
-                     (size_t)c->feat_cap * kOriBins, c->d_desc, (size_t)c->feat_cap * 128, c->d_pq,
-                     (size_t)c->feat_cap * 128, c->d_fscale, c->feat_cap, c->feat_cap, B, c->prm.precision, s);
+        StageScope sc(c, SG_ST_DESCR, 2);
+        launch_feat_gather(c->d_kp, c->cand_cap, c->d_kpsrc, c->feat_cap, c->d_fsrc, c->feat_cap, n_feat, c->d_ori,
+                           (size_t)c->feat_cap * kOriBins, c->d_frec, c->feat_cap, c->d_fscale, c->feat_cap,
+                           c->feat_cap, B, s);
+        launch_descr(tab, c->d_frec, c->feat_cap, n_feat, c->d_desc, (size_t)c->feat_cap * 128, c->d_pq,
+                     (size_t)c->feat_cap * 128, c->feat_cap, B, c->prm.precision, s);
     }
 }
 
@@ -524,7 +528,7 @@ int sg_destroy(sg_ctx *c)
         (void)hipStreamSynchronize(c->stream);
     void *bufs[] = {c->d_in, c->d_up, c->d_tmp, c->d_levels, c->d_words, c->d_vwords, c->d_pwords, c->d_chunks,
                     c->d_cand, c->d_kpsrc, c->d_fsrc, c->d_rank, c->d_kp, c->d_ori, c->d_pq, c->d_fscale, c->d_desc,
-                    c->d_counts, c->d_ctr, c->d_overflow, c->d_out, c->d_outcounts, c->d_bwork, c->d_blist, c->d_rtot};
+                    c->d_counts, c->d_ctr, c->d_overflow, c->d_out, c->d_outcounts, c->d_bwork, c->d_blist, c->d_rtot, c->d_frec};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -634,6 +638,7 @@ int sg_create(const sg_params *p, sg_ctx **out)
     ALLOC(c->d_rank, sizeof(unsigned int) * (size_t)c->feat_cap * B);
     ALLOC(c->d_ori, sizeof(double) * (size_t)c->feat_cap * kOriBins * B);
     ALLOC(c->d_fscale, sizeof(double) * (size_t)c->feat_cap * B);
+    ALLOC(c->d_frec, sizeof(FeatRec) * (size_t)c->feat_cap * B);
     ALLOC(c->d_desc, (size_t)c->feat_cap * 128 * B);
     if (p->keep_prequant)
         ALLOC(c->d_pq, sizeof(double) * (size_t)c->feat_cap * 128 * B);

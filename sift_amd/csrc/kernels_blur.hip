@@ -539,7 +539,7 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
     const int strips = (cols + TW - 1) / TW;
     // segment length: several thousand blocks so that the chip stays full through the tail, but segments
     // long enough that the 2R halo rows (re-read and row-filtered again) stay a small share on large planes
-    long long want = 6144;
+    long long want = 1536;
     long long per_row_blocks = (long long)strips * B;
     int seg = (int)(((long long)rows * per_row_blocks + want - 1) / want);
     if (seg < 16)

@@ -5,9 +5,9 @@ Metric (BASELINE.json): 1080p images/s (keypoints + descriptors), whole job over
 rate of the blur kernels.  Workload: 1920x1080 synthetic frames (5-octave value noise, seeds 1000...),
 resident in HBM before the timed region; one step = one batch of `--batch` frames through the whole path
 (gray/upsample/blur, Gaussian pyramid, fused DoG+extrema, refinement, orientation, descriptors, scale
-ordering, 144-byte packed features).  With the defaults 16 steps x 16 frames = the 256-frame batch config.
+ordering, 144-byte packed features).  With the defaults 8 steps x 32 frames = the 256-frame batch config.
 
-  python bench.py --gpus 1 --steps 16 --warmup 2
+  python bench.py --gpus 1 --steps 8 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -46,14 +46,14 @@ def octave_pixels(w, h):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64")
     ap.add_argument("--pool", type=int, default=256, help="distinct frames kept resident per GPU")
-    ap.add_argument("--cap", type=int, default=32768, help="packed-feature capacity per frame")
+    ap.add_argument("--cap", type=int, default=26624, help="packed-feature capacity per frame")
     ap.add_argument("--contexts", type=int, default=1,
                     help="batches in flight per GPU (1: per-kernel event times are undisturbed; 2 overlaps\n"
                          "memory-bound and compute-bound kernels of consecutive batches for a few % more throughput)")

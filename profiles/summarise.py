@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Summarise gpurun_out/prof_<tag>/ (written by profiles/collect.sh) into profiles/<tag>/:
+kernel_stats.csv (rocprofv3 --stats, verbatim), summary.md, traffic.json (HBM-side bytes per launch per kernel).
+
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a 128-byte request of a wide (16 B/lane)
+streaming read as 64 bytes, so it is doubled for the blur kernels, whose reads are of that shape."""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles", tag)
+os.makedirs(dst, exist_ok=True)
+
+
+def short(name):
+    return name.split("(")[0].replace("void ", "").strip()
+
+
+stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, "kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench_stats.json"), os.path.join(dst, "bench_under_rocprof.json"))
+
+
+def pmc(kind):
+    f = glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv"))[0]
+    acc = defaultdict(lambda: [0.0, set()])
+    for r in csv.DictReader(open(f)):
+        k = short(r["Kernel_Name"])
+        acc[k][0] += float(r["Counter_Value"])
+        acc[k][1].add(r["Dispatch_Id"])
+    return {k: (v[0] * 1024.0, len(v[1])) for k, v in acc.items()}
+
+
+fetch, write = pmc("fetch"), pmc("write")
+rows = list(csv.DictReader(open(stats)))
+traffic = {}
+lines = ["# rocprofv3 summary (%s): `python bench.py` (8 steps x 32 frames 1920x1080, f64, one context)" % tag, "",
+         "| kernel | calls | avg us | total ms | % | FETCH_SIZE MB/launch (x2 for blur) | WRITE_SIZE MB/launch |", "|---|---|---|---|---|---|---|"]
+for r in rows[:24]:
+    k = short(r["Name"])
+    fb, fn = fetch.get(k, (0.0, 0))
+    wb, wn = write.get(k, (0.0, 0))
+    mult = 2.0 if "blur_fused" in k or "blur_row" in k or "blur_col" in k else 1.0
+    f_l = mult * fb / fn if fn else 0.0
+    w_l = wb / wn if wn else 0.0
+    traffic[k] = {"fetch_bytes_per_launch": f_l, "write_bytes_per_launch": w_l, "fetch_correction": mult,
+                  "hbm_bytes_per_launch": f_l + w_l}
+    lines.append("| `%s` | %s | %.1f | %.2f | %s | %.1f | %.1f |" % (k[:70], r["Calls"], float(r["AverageNs"]) / 1e3,
+                                                                     float(r["TotalDurationNs"]) / 1e6, r["Percentage"],
+                                                                     f_l / 1e6, w_l / 1e6))
+open(os.path.join(dst, "summary.md"), "w").write("\n".join(lines) + "\n")
+json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+print("\n".join(lines))

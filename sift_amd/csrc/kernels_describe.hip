@@ -3,10 +3,6 @@
 #include "sg_internal.h"
 #include "sg_math.h"
 
-#ifndef SG_ABL
-#define SG_ABL 0
-#endif
-
 namespace sg {
 
 #define SG_PI 3.1415926535897932384626433832795 /* CV_PI */
@@ -119,10 +115,7 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
             // sample s -> (i = s / W - radius: x offset, the reference's outer loop; jj = s % W - radius: y offset)
             int qi = lane / W, qj = lane - qi * W;
             const int dq = 64 / W, dr = 64 - dq * W;
-#if SG_ABL == 11
-            double abl_o = 0;
-#endif
-            for (int s = lane; s < (SG_ABL == 13 ? 0 : total); s += 64) {
+            for (int s = lane; s < total; s += 64) {
                 const int i = qi - radius, jj = qj - radius;
                 double dx, dy;
                 bool ok;
@@ -136,21 +129,12 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
                     ok = grad_at(g, rows, cols, pitch, r.x + i, r.y + jj, dx, dy);
                 }
                 if (ok) {
-#if SG_ABL == 12
-                    double mag = dx * dx + dy * dy;
-                    double ori = dx * 3 + dy;
-#else
                     double mag = sg_sqrt(dx * dx + dy * dy);
                     double ori = sg_atan2(dy, dx);
-#endif
                     double weight = use_tab ? E[abs(i)] * E[abs(jj)] : exp((i * i + jj * jj) * econs);
                     int bin = (int)rint(kOriBins * (SG_PI - ori) / PI2);
                     bin = bin < kOriBins ? bin : 0;
-#if SG_ABL == 11
-                    abl_o += mag * weight + bin;
-#else
                     lds_add(&hc[bin], mag * weight);
-#endif
                 }
                 qi += dq;
                 qj += dr;
@@ -159,9 +143,6 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
                     qi++;
                 }
             }
-#if SG_ABL == 11
-            if (abl_o == 123.456) hs[0] = 1;
-#endif
         }
         wave_lds_fence();
         const bool binlane = lane < kOriBins;
@@ -304,9 +285,6 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const FeatRec *fre
             etab[tid] = exp((tid * tid) * wcons);
         const float cf = (float)cos_ori, sf = (float)sin_ori, inv_shw_f = (float)inv_shw;
         double *h = hist[wave * kDescCopies + (lane & (kDescCopies - 1))];
-#if SG_ABL == 1
-        double abl_acc = 0.0;
-#endif
         unsigned short *q = queue[wave];
         // sample s -> (i = s / W - radius: y offset, the reference's outer loop; jj = s % W - radius: x offset)
         int qi = tid / W, qj = tid - qi * W;
@@ -342,9 +320,6 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const FeatRec *fre
             }
             __syncthreads();
             // pass 2: double arithmetic on the queued samples
-#if SG_ABL == 3
-            count = 0;
-#endif
             for (int e = lane; e < count; e += 64) {
                 const unsigned int pk = q[e];
                 const int i = (int)(pk >> 8) - radius, jj = (int)(pk & 255u) - radius;
@@ -356,13 +331,8 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const FeatRec *fre
                     const T *p = g + (size_t)(r.y + i) * pitch + (r.x + jj); // validity was tested in pass 1
                     double dx = (double)p[1] - (double)p[-1];
                     double dy = (double)p[pitch] - (double)p[-pitch];
-#if SG_ABL == 2
-                    double grad_mag = dx * dx + dy * dy;
-                    double grad_ori = (SG_PI - (dy > 0 ? dx * 8 : -3 + dy * 8)) - ori;
-#else
                     double grad_mag = sg_sqrt(dx * dx + dy * dy);
                     double grad_ori = (SG_PI - sg_atan2(dy, dx)) - ori;
-#endif
                     while (grad_ori < 0.0)
                         grad_ori += PI2;
                     while (grad_ori >= PI2)
@@ -387,11 +357,7 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const FeatRec *fre
                                     for (int oo = 0; oo <= 1; oo++) {
                                         int ob = (o0 + oo) & 7;
                                         double v_o = v_c * ((oo == 0) ? 1.0 - d_o : d_o);
-#if SG_ABL == 1
-                                        abl_acc += v_o;
-#else
                                         lds_add(&h[(rb * 4 + cb) * 8 + ob], v_o);
-#endif
                                     }
                                 }
                             }
@@ -425,9 +391,6 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const FeatRec *fre
             }
             desc[(size_t)b * desc_img + (size_t)f * 128 + tid] = (uint8_t)qv;
         }
-#if SG_ABL == 1
-        if (abl_acc == 123.456) desc[0] = 1;
-#endif
         __syncthreads();
     }
 }

@@ -18,6 +18,7 @@ Rank 0 prints one JSON line.
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -41,6 +42,28 @@ def octave_pixels(w, h):
         if rows > 1 and cols > 1:
             rows, cols = rows // 2, cols // 2
     return px
+
+
+def measured_traffic(kernel, tname, batch, width, height):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r*/traffic.json, written by
+    profiles/summarise.py from separate FETCH_SIZE and WRITE_SIZE runs of this same command); None when no pass
+    was collected for this kernel at this workload."""
+    import glob
+    m = re.match(r"blur_fused_k<(\w+),R=(\d+)>", kernel)
+    if not m:
+        return None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        cfg = t.get("_config", {})
+        if (cfg.get("batch"), cfg.get("width"), cfg.get("height")) != (batch, width, height):
+            continue
+        for name, d in t.items():
+            if name.startswith("sg::blur_fused_k<%s, %s," % (m.group(1), m.group(2))):
+                return d["hbm_bytes_per_launch"]
+    return None
 
 
 def main():
@@ -228,7 +251,7 @@ def main():
             "kernel": dom + (" (row + column pass of a %d-tap Gaussian in one launch; all octaves' launches)" % e["taps"]
                              if fused else " (%d-tap pass; all octaves' launches)" % e["taps"]),
             "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
-            "traffic": None,
+            "traffic": measured_traffic(dom, tname, B, W, H),
             "launches": e["launches"], "avg_launch_us": 1e3 * e["ms"] / e["launches"],
             "algorithmic_bytes_per_launch": e["bytes"] / e["launches"],
             "all_blur_launches_GBps": (tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else None,

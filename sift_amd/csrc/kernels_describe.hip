@@ -212,45 +212,75 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
 }
 
 // ---- descriptors -----------------------------------------------------------------------------------------
-// One 256-thread workgroup per feature.  CalculateDescrHist + InterpHistEntry (sift.cpp:1352-1535).
-// Pass 1 walks the (2r+1)^2 window with a cheap float test and queues, per wave, the samples that may lie
-// in the rotated 4x4 grid (a superset: the float test has a margin); pass 2 takes the queued samples 64 at
-// a time, repeats the reference's acceptance test in double and spreads each accepted sample trilinearly
-// into wave-private 4x4x8 histograms with LDS double atomics (four copies per wave, lane & 3, added in a
-// fixed order), so that the expensive part runs with full lanes.  Against the reference's per-sample
-// formulas two things are algebraically regrouped (results agree to ~1e-15 relative): the rotated
-// coordinates multiply by 1/shw instead of dividing, and the window weight exp(-(rx^2+ry^2)/8), with
-// rx^2+ry^2 = (i^2+j^2)/shw^2, is E[|i|]*E[|j|] from a per-feature table E[k] = exp(-k^2/(8 shw^2)).
-// HistToDescriptor (sift.cpp:1567-1597): normalise, clamp at 0.2, normalise, min(255,(int)(512 v)).
+// One wave (a 64-thread workgroup) per feature, nothing shared between waves and no barriers.
+// CalculateDescrHist + InterpHistEntry (sift.cpp:1352-1535).  The samples that can fall into the rotated
+// 4x4 grid form, in every window row, one interval of columns; the lanes compute those intervals (one row per
+// lane, a superset by a 1e-6 px margin, clipped to the pixels that have a gradient), the wave then writes the
+// intervals' (row, column) pairs into a queue, and takes the queued samples 64 at a time: the reference's
+// acceptance test in double, gradient, and the trilinear spread into 4x4x8 histograms with LDS double
+// atomics (four copies, lane & 3, at a stride that puts them in different banks; added in a fixed order).
+// So the expensive part runs with full lanes and the window's corners outside the grid are never visited.
+// Against the reference's per-sample formulas three things are algebraically regrouped (results agree to
+// ~1e-15 relative): the rotated coordinates use cos/shw and sin/shw in fused multiply-adds, the window weight
+// exp(-(rx^2+ry^2)/8), with rx^2+ry^2 = (i^2+j^2)/shw^2, is E[|i|]*E[|j|] from a per-feature table
+// E[k] = exp(-k^2/(8 shw^2)), and the angle wrap is one conditional add and subtract (its argument lies in
+// (-pi, 3pi]).  HistToDescriptor (sift.cpp:1567-1597): normalise, clamp at 0.2, normalise, min(255,(int)(512 v)).
 
-constexpr int kDescRoundIters = 24;              // pass-1 iterations per round
-constexpr int kDescQueue = kDescRoundIters * 64; // queue entries per wave
+constexpr int kDescQueue = 1536; // queue entries (samples) per round
 constexpr int kDescCopies = 4;
+constexpr int kDescCopyStride = 130; // doubles; 128 bins + 2, so that the copies start 4 banks apart
 constexpr int kDescTab = 128;
+constexpr int kDescPackRadius = 127; // largest radius whose (row, column) pair fits the 16-bit queue entry
 
-__device__ __forceinline__ double block_sum_128(double v, double *red, int tid)
+__device__ __forceinline__ double wave_sum(double v)
 {
-    // v is meaningful on threads 0..127 (waves 0 and 1); result broadcast to every thread
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1)
         v += __shfl_xor(v, d);
-    __syncthreads();
-    if ((tid & 63) == 0)
-        red[tid >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1];
+    return v;
+}
+
+// Columns [lo, lo+cnt) (as offsets jj from the feature) of window row i that can pass the acceptance test
+// |c*jj - s*i| < T and |s*jj + c*i| < T, T = 2.5*shw + margin, and whose pixel has a gradient.
+__device__ __forceinline__ void descr_row_span(int i, double c, double s, double inv_c, double inv_s, bool c_ok,
+                                               bool s_ok, double T, int radius, int x0, int y0, int rows, int cols,
+                                               int &lo, int &cnt)
+{
+    double lo_d = -(double)radius, hi_d = (double)radius;
+    const double b1 = -s * i, b2 = c * i;
+    bool empty = false;
+    if (c_ok) {
+        const double p = (-T - b1) * inv_c, q = (T - b1) * inv_c;
+        lo_d = fmax(lo_d, fmin(p, q));
+        hi_d = fmin(hi_d, fmax(p, q));
+    } else {
+        empty = !(fabs(b1) < T);
+    }
+    if (s_ok) {
+        const double p = (-T - b2) * inv_s, q = (T - b2) * inv_s;
+        lo_d = fmax(lo_d, fmin(p, q));
+        hi_d = fmin(hi_d, fmax(p, q));
+    } else {
+        empty = empty || !(fabs(b2) < T);
+    }
+    const int y = y0 + i;
+    empty = empty || !(y > 0 && y < rows - 1) || !(lo_d <= hi_d);
+    int l = (int)ceil(lo_d), h = (int)floor(hi_d);
+    l = max(l, 1 - x0);
+    h = min(h, cols - 2 - x0);
+    lo = l;
+    cnt = empty ? 0 : max(h - l + 1, 0);
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const FeatRec *frec, size_t frec_img,
-                                               const unsigned int *feat_count, uint8_t *desc, size_t desc_img,
-                                               double *prequant, size_t pq_img, unsigned int cap)
+__global__ __launch_bounds__(64) void descr_k(OctaveTab tab, const FeatRec *frec, size_t frec_img,
+                                              const unsigned int *feat_count, uint8_t *desc, size_t desc_img,
+                                              double *prequant, size_t pq_img, unsigned int cap)
 {
-    __shared__ double hist[4 * kDescCopies][128];
+    __shared__ double hist[kDescCopies * kDescCopyStride];
     __shared__ double etab[kDescTab];
-    __shared__ double red[4];
-    __shared__ unsigned short queue[4][kDescQueue];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ unsigned short queue[kDescQueue];
+    const int lane = threadIdx.x;
     const int b = blockIdx.y;
     const unsigned int n = min(feat_count[b], cap);
     const double PI2 = SG_PI * 2;
@@ -266,83 +296,105 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const FeatRec *fre
             nxt = fr[f + gridDim.x];
         const double ori = r.ori;
         const int o = r.octave;
-        const T *g = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o];
         const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
-
-        double *hflat = &hist[0][0]; // 16 x 128 doubles, 8 per thread
-#pragma unroll
-        for (int q = 0; q < 4 * kDescCopies * 128 / 256; q++)
-            hflat[tid + 256 * q] = 0.0;
-
         const double cos_ori = r.cos_ori, sin_ori = r.sin_ori; // cos(ori), sin(ori) (sift.cpp:1474-1475)
-        const double shw = 3 * r.oscale;                             // DESCR_SCALE_ADJUST * octave_scale
+        const double shw = 3 * r.oscale;                       // DESCR_SCALE_ADJUST * octave_scale
         const double inv_shw = 1.0 / shw;
         const int radius = (int)((shw * sqrt(2.0) * (4 + 1)) / 2.0); // truncating cast (sift.cpp:1488)
-        const int W = 2 * radius + 1, total = W * W;
+        const int W = 2 * radius + 1;
         const double wcons = -0.125 * inv_shw * inv_shw; // -1/(2*(0.5*4)^2) / shw^2
         const bool use_tab = radius < kDescTab;
-        if (tid < kDescTab)
-            etab[tid] = exp((tid * tid) * wcons);
-        const float cf = (float)cos_ori, sf = (float)sin_ori, inv_shw_f = (float)inv_shw;
-        double *h = hist[wave * kDescCopies + (lane & (kDescCopies - 1))];
-        unsigned short *q = queue[wave];
-        // sample s -> (i = s / W - radius: y offset, the reference's outer loop; jj = s % W - radius: x offset)
-        int qi = tid / W, qj = tid - qi * W;
-        const int dq = 256 / W, dr = 256 - dq * W;
-        __syncthreads();
-        for (int base = 0; base < total; base += 256 * kDescRoundIters) {
-            // pass 1: float pre-test with a margin, pixel validity, wave-ordered queue
-            int count = 0;
-            const int round_end = min(total, base + 256 * kDescRoundIters);
-            const int iters = (round_end - base + 255) / 256;
-            for (int it = 0; it < iters; it++) {
-                const int s = base + it * 256 + tid;
-                bool cand = false;
-                const int i = qi - radius, jj = qj - radius;
-                if (s < round_end) {
-                    float rx = (cf * jj - sf * i) * inv_shw_f, ry = (sf * jj + cf * i) * inv_shw_f;
-                    const int x = r.x + jj, y = r.y + i;
-                    cand = rx > -2.5001f && rx < 2.5001f && ry > -2.5001f && ry < 2.5001f && x > 0 && x < cols - 1 &&
-                           y > 0 && y < rows - 1;
-                }
-                unsigned long long m = __ballot(cand);
-                if (cand) {
-                    int pos = count + __popcll(m & ((1ull << lane) - 1ull));
-                    q[pos] = (unsigned short)(((i + radius) << 8) | (jj + radius));
-                }
-                count += __popcll(m);
-                qi += dq;
-                qj += dr;
-                if (qj >= W) {
-                    qj -= W;
-                    qi++;
+        const bool packed = radius <= kDescPackRadius;
+        // Sample addresses are unsigned offsets from the pixel one row above and one column left of the
+        // window's first sample (that pixel itself may lie outside the image; it is never read).
+        const T *g0 = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o] +
+                      ((ptrdiff_t)(r.y - radius - 1) * pitch + (r.x - radius - 1));
+
+#pragma unroll
+        for (int q = 0; q < (kDescCopies * kDescCopyStride + 63) / 64; q++)
+            if (lane + 64 * q < kDescCopies * kDescCopyStride)
+                hist[lane + 64 * q] = 0.0;
+        etab[lane] = exp((lane * lane) * wcons);
+        if (radius >= 64)
+            etab[lane + 64] = exp(((lane + 64) * (lane + 64)) * wcons);
+
+        const double cs = cos_ori * inv_shw, ss = sin_ori * inv_shw;
+        const double Tm = 2.5 * shw + 1e-6;
+        const bool c_ok = fabs(cos_ori) > 1e-9, s_ok = fabs(sin_ori) > 1e-9;
+        const double inv_c = c_ok ? 1.0 / cos_ori : 0.0, inv_s = s_ok ? 1.0 / sin_ori : 0.0;
+        // row spans: lane L holds rows L, L+64, L+128, L+192 as (cnt << 8) | (lo + radius)
+        unsigned int span[4] = {0u, 0u, 0u, 0u};
+        if (packed) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int row = lane + 64 * k;
+                if (64 * k < W && row < W) {
+                    int lo, cnt;
+                    descr_row_span(row - radius, cos_ori, sin_ori, inv_c, inv_s, c_ok, s_ok, Tm, radius, r.x, r.y, rows,
+                                   cols, lo, cnt);
+                    span[k] = cnt > 0 ? ((unsigned int)cnt << 8) | (unsigned int)(lo + radius) : 0u;
                 }
             }
-            __syncthreads();
-            // pass 2: double arithmetic on the queued samples
+        }
+        double *h = hist + (lane & (kDescCopies - 1)) * kDescCopyStride;
+        wave_lds_fence();
+
+        int row = 0;
+        while (row < W) {
+            // ---- fill: whole rows while they fit (packed), or one row's span computed on the spot ----
+            int count = 0, big_lo = 0;
+            const int big_row = row;
+            if (packed) {
+                while (row < W) {
+                    const unsigned int sv = row < 64 ? span[0] : (row < 128 ? span[1] : (row < 192 ? span[2] : span[3]));
+                    const unsigned int sp = (unsigned int)__builtin_amdgcn_readlane((int)sv, row & 63);
+                    const int cnt = (int)(sp >> 8);
+                    if (count + cnt > kDescQueue)
+                        break;
+                    const unsigned int first = ((unsigned int)row << 8) | (sp & 255u);
+                    for (int c0 = lane; c0 < cnt; c0 += 64)
+                        queue[count + c0] = (unsigned short)(first + (unsigned int)c0);
+                    count += cnt;
+                    row++;
+                }
+                wave_lds_fence();
+            } else {
+                descr_row_span(row - radius, cos_ori, sin_ori, inv_c, inv_s, c_ok, s_ok, Tm, radius, r.x, r.y, rows, cols,
+                               big_lo, count);
+                big_lo += radius;
+                row++;
+            }
+            // ---- drain: double arithmetic on the listed samples ----
             for (int e = lane; e < count; e += 64) {
-                const unsigned int pk = q[e];
-                const int i = (int)(pk >> 8) - radius, jj = (int)(pk & 255u) - radius;
-                double rot_x = (cos_ori * jj - sin_ori * i) * inv_shw;
-                double rot_y = (sin_ori * jj + cos_ori * i) * inv_shw;
-                double xbin = rot_x + 4 / 2 - 0.5;
-                double ybin = rot_y + 4 / 2 - 0.5;
+                unsigned int ri, ci; // row and column inside the window
+                if (packed) {
+                    const unsigned int pk = queue[e];
+                    ri = pk >> 8;
+                    ci = pk & 255u;
+                } else {
+                    ri = (unsigned int)big_row;
+                    ci = (unsigned int)(big_lo + e);
+                }
+                const int i = (int)ri - radius, jj = (int)ci - radius;
+                const double xbin = __builtin_fma(cs, (double)jj, __builtin_fma(-ss, (double)i, 1.5));
+                const double ybin = __builtin_fma(ss, (double)jj, __builtin_fma(cs, (double)i, 1.5));
                 if (xbin > -1.0 && xbin < 4 && ybin > -1.0 && ybin < 4) {
-                    const T *p = g + (size_t)(r.y + i) * pitch + (r.x + jj); // validity was tested in pass 1
+                    const T *p = g0 + ((ri + 1u) * (unsigned int)pitch + (ci + 1u));
                     double dx = (double)p[1] - (double)p[-1];
                     double dy = (double)p[pitch] - (double)p[-pitch];
                     double grad_mag = sg_sqrt(dx * dx + dy * dy);
                     double grad_ori = (SG_PI - sg_atan2(dy, dx)) - ori;
-                    while (grad_ori < 0.0)
+                    if (grad_ori < 0.0)
                         grad_ori += PI2;
-                    while (grad_ori >= PI2)
+                    if (grad_ori >= PI2)
                         grad_ori -= PI2;
                     double obin = grad_ori * (8 / PI2);
                     double weight = use_tab ? etab[abs(i)] * etab[abs(jj)] : exp((i * i + jj * jj) * wcons);
                     double mag = grad_mag * weight;
                     // InterpHistEntry
-                    int r0 = (int)floor(ybin), c0 = (int)floor(xbin), o0 = (int)floor(obin);
-                    double d_r = ybin - r0, d_c = xbin - c0, d_o = obin - o0;
+                    const double fr_ = floor(ybin), fc_ = floor(xbin), fo_ = floor(obin);
+                    const int r0 = (int)fr_, c0 = (int)fc_, o0 = (int)fo_;
+                    const double d_r = ybin - fr_, d_c = xbin - fc_, d_o = obin - fo_;
 #pragma unroll
                     for (int rr = 0; rr <= 1; rr++) {
                         int rb = r0 + rr;
@@ -365,33 +417,42 @@ __global__ __launch_bounds__(256) void descr_k(OctaveTab tab, const FeatRec *fre
                     }
                 }
             }
-            __syncthreads();
+            wave_lds_fence();
         }
-        double v = 0.0;
-        if (tid < 128) {
+
+        // lane L finishes bins 2L and 2L+1
+        double v0 = 0.0, v1 = 0.0;
 #pragma unroll
-            for (int q2 = 0; q2 < 4 * kDescCopies; q2++)
-                v += hist[q2][tid];
+        for (int q2 = 0; q2 < kDescCopies; q2++) {
+            v0 += hist[q2 * kDescCopyStride + 2 * lane];
+            v1 += hist[q2 * kDescCopyStride + 2 * lane + 1];
         }
-        double len_sq = block_sum_128(tid < 128 ? v * v : 0.0, red, tid);
-        double len_inv = 1.0 / sqrt(len_sq);
-        v *= len_inv;
-        if (v > 0.2) // DESCR_MAG_THR
-            v = 0.2;
-        len_sq = block_sum_128(tid < 128 ? v * v : 0.0, red, tid);
-        len_inv = 1.0 / sqrt(len_sq);
-        v *= len_inv;
-        if (tid < 128) {
-            if (prequant)
-                prequant[(size_t)b * pq_img + (size_t)f * 128 + tid] = v;
-            int qv = 0;
-            if (v == v) { // an all-zero window gives 0/0; keep such a descriptor at zero
-                qv = (int)(512.0 * v); // INT_DESCR_FCTR, truncating
-                qv = qv < 255 ? qv : 255;
-            }
-            desc[(size_t)b * desc_img + (size_t)f * 128 + tid] = (uint8_t)qv;
+        double len_inv = 1.0 / sqrt(wave_sum(v0 * v0 + v1 * v1));
+        v0 *= len_inv;
+        v1 *= len_inv;
+        v0 = v0 > 0.2 ? 0.2 : v0; // DESCR_MAG_THR
+        v1 = v1 > 0.2 ? 0.2 : v1;
+        len_inv = 1.0 / sqrt(wave_sum(v0 * v0 + v1 * v1));
+        v0 *= len_inv;
+        v1 *= len_inv;
+        if (prequant) {
+            double2 pq;
+            pq.x = v0;
+            pq.y = v1;
+            *reinterpret_cast<double2 *>(prequant + (size_t)b * pq_img + (size_t)f * 128 + 2 * lane) = pq;
         }
-        __syncthreads();
+        int q0 = 0, q1 = 0;
+        if (v0 == v0) { // an all-zero window gives 0/0; keep such a descriptor at zero
+            q0 = (int)(512.0 * v0); // INT_DESCR_FCTR, truncating
+            q0 = q0 < 255 ? q0 : 255;
+        }
+        if (v1 == v1) {
+            q1 = (int)(512.0 * v1);
+            q1 = q1 < 255 ? q1 : 255;
+        }
+        *reinterpret_cast<unsigned short *>(desc + (size_t)b * desc_img + (size_t)f * 128 + 2 * lane) =
+            (unsigned short)(q0 | (q1 << 8));
+        wave_lds_fence(); // the histograms are cleared for the next feature
     }
 }
 
@@ -399,16 +460,16 @@ void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_str
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
                   int B, int prec, hipStream_t s)
 {
-    unsigned int blocks = cap < 4096 ? cap : 4096;
+    unsigned int blocks = cap < 16384 ? cap : 16384;
     if (blocks == 0)
         return;
     dim3 g(blocks, B);
     if (prec == SG_F64)
-        descr_k<double><<<g, 256, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,
-                                          pq_img_stride, cap);
-    else
-        descr_k<float><<<g, 256, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,
+        descr_k<double><<<g, 64, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,
                                          pq_img_stride, cap);
+    else
+        descr_k<float><<<g, 64, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,
+                                        pq_img_stride, cap);
 }
 
 // One thread per feature: follows feat_src -> kp_src -> kp / ori_tmp once and leaves a compact record.

@@ -226,10 +226,11 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
 // E[k] = exp(-k^2/(8 shw^2)), and the angle wrap is one conditional add and subtract (its argument lies in
 // (-pi, 3pi]).  HistToDescriptor (sift.cpp:1567-1597): normalise, clamp at 0.2, normalise, min(255,(int)(512 v)).
 
-constexpr int kDescQueue = 1536; // queue entries (samples) per round
+constexpr int kDescQueue = 960;  // queue entries (samples) per round
 constexpr int kDescCopies = 4;
 constexpr int kDescCopyStride = 130; // doubles; 128 bins + 2, so that the copies start 4 banks apart
-constexpr int kDescTab = 128;
+constexpr int kDescTab = 128;      // weight table entries of the wide-window variant
+constexpr int kDescTabSmall = 64;  // ... of the common variant (every radius below 64)
 constexpr int kDescPackRadius = 127; // largest radius whose (row, column) pair fits the 16-bit queue entry
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -272,13 +273,17 @@ __device__ __forceinline__ void descr_row_span(int i, double c, double s, double
     cnt = empty ? 0 : max(h - l + 1, 0);
 }
 
-template <typename T>
-__global__ __launch_bounds__(64) void descr_k(OctaveTab tab, const FeatRec *frec, size_t frec_img,
-                                              const unsigned int *feat_count, uint8_t *desc, size_t desc_img,
-                                              double *prequant, size_t pq_img, unsigned int cap)
+#ifndef SG_DESCR_WPE
+#define SG_DESCR_WPE 5
+#endif
+template <typename T, bool BIG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE, SG_DESCR_WPE))) void descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img,
+                                              const unsigned int *__restrict__ feat_count,
+                                              uint8_t *__restrict__ desc, size_t desc_img,
+                                              double *__restrict__ prequant, size_t pq_img, unsigned int cap)
 {
     __shared__ double hist[kDescCopies * kDescCopyStride];
-    __shared__ double etab[kDescTab];
+    __shared__ double etab[BIG ? kDescTab : kDescTabSmall];
     __shared__ unsigned short queue[kDescQueue];
     const int lane = threadIdx.x;
     const int b = blockIdx.y;
@@ -303,8 +308,9 @@ __global__ __launch_bounds__(64) void descr_k(OctaveTab tab, const FeatRec *frec
         const int radius = (int)((shw * sqrt(2.0) * (4 + 1)) / 2.0); // truncating cast (sift.cpp:1488)
         const int W = 2 * radius + 1;
         const double wcons = -0.125 * inv_shw * inv_shw; // -1/(2*(0.5*4)^2) / shw^2
-        const bool use_tab = radius < kDescTab;
-        const bool packed = radius <= kDescPackRadius;
+        // BIG is chosen on the host from the largest radius the parameters allow (64 or more): only then can a
+        // window be too wide for the 16-bit queue entries and the 128-entry weight table.
+        const bool packed = !BIG || radius <= kDescPackRadius;
         // Sample addresses are unsigned offsets from the pixel one row above and one column left of the
         // window's first sample (that pixel itself may lie outside the image; it is never read).
         const T *g0 = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o] +
@@ -315,8 +321,9 @@ __global__ __launch_bounds__(64) void descr_k(OctaveTab tab, const FeatRec *frec
             if (lane + 64 * q < kDescCopies * kDescCopyStride)
                 hist[lane + 64 * q] = 0.0;
         etab[lane] = exp((lane * lane) * wcons);
-        if (radius >= 64)
+        if (BIG && radius >= 64)
             etab[lane + 64] = exp(((lane + 64) * (lane + 64)) * wcons);
+        static_assert(kDescTab == 128 && kDescPackRadius < kDescTab, "the table covers every packed radius");
 
         const double cs = cos_ori * inv_shw, ss = sin_ori * inv_shw;
         const double Tm = 2.5 * shw + 1e-6;
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(64) void descr_k(OctaveTab tab, const FeatRec *frec
                     row++;
                 }
                 wave_lds_fence();
-            } else {
+            } else if (BIG) {
                 descr_row_span(row - radius, cos_ori, sin_ori, inv_c, inv_s, c_ok, s_ok, Tm, radius, r.x, r.y, rows, cols,
                                big_lo, count);
                 big_lo += radius;
@@ -389,7 +396,11 @@ __global__ __launch_bounds__(64) void descr_k(OctaveTab tab, const FeatRec *frec
                     if (grad_ori >= PI2)
                         grad_ori -= PI2;
                     double obin = grad_ori * (8 / PI2);
-                    double weight = use_tab ? etab[abs(i)] * etab[abs(jj)] : exp((i * i + jj * jj) * wcons);
+                    double weight;
+                    if (BIG && !packed)
+                        weight = exp((i * i + jj * jj) * wcons);
+                    else
+                        weight = etab[abs(i)] * etab[abs(jj)];
                     double mag = grad_mag * weight;
                     // InterpHistEntry
                     const double fr_ = floor(ybin), fc_ = floor(xbin), fo_ = floor(obin);
@@ -458,18 +469,28 @@ __global__ __launch_bounds__(64) void descr_k(OctaveTab tab, const FeatRec *frec
 
 void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_stride, const unsigned int *feat_count,
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
-                  int B, int prec, hipStream_t s)
+                  int max_radius, int B, int prec, hipStream_t s)
 {
     unsigned int blocks = cap < 16384 ? cap : 16384;
     if (blocks == 0)
         return;
     dim3 g(blocks, B);
-    if (prec == SG_F64)
-        descr_k<double><<<g, 64, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,
-                                         pq_img_stride, cap);
-    else
-        descr_k<float><<<g, 64, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,
-                                        pq_img_stride, cap);
+    const bool big = max_radius >= kDescTabSmall;
+#define SG_DESCR_LAUNCH(TT, BB)                                                                                       \
+    descr_k<TT, BB><<<g, 64, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,         \
+                                     pq_img_stride, cap)
+    if (prec == SG_F64) {
+        if (big)
+            SG_DESCR_LAUNCH(double, true);
+        else
+            SG_DESCR_LAUNCH(double, false);
+    } else {
+        if (big)
+            SG_DESCR_LAUNCH(float, true);
+        else
+            SG_DESCR_LAUNCH(float, false);
+    }
+#undef SG_DESCR_LAUNCH
 }
 
 // One thread per feature: follows feat_src -> kp_src -> kp / ori_tmp once and leaves a compact record.

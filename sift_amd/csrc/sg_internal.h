@@ -105,9 +105,10 @@ void launch_feat_gather(const KpRec *kp, size_t kp_img_stride, const unsigned in
                         const unsigned int *feat_src, size_t fsrc_img_stride, const unsigned int *feat_count,
                         const double *ori_tmp, size_t ori_img_stride, FeatRec *frec, size_t frec_img_stride,
                         double *fscale, size_t fs_img_stride, unsigned int cap, int B, hipStream_t s);
+// max_radius: an upper bound of the features' window radii (selects the kernel variant for very wide windows)
 void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_stride, const unsigned int *feat_count,
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
-                  int B, int prec, hipStream_t s);
+                  int max_radius, int B, int prec, hipStream_t s);
 // bwork: [B][2][kRankBuckets] scratch, blist: [B][cap] scratch, scratch_totals: [B], overflow_dummy: [1]
 void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
                  size_t rank_img_stride, unsigned int *bwork, unsigned int *blist, unsigned int *scratch_totals,

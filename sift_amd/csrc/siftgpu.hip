@@ -332,7 +332,20 @@ static void orient_phase(sg_ctx *c, const OctaveTab &tab, int B)
     }
 }
 
-static void descr_phase(sg_ctx *c, const OctaveTab &tab, int B)
+// Descriptor window radius for an octave-relative scale (reference sift/sift.cpp:1488).
+static int descr_radius(double oscale)
+{
+    const double r = (3.0 * oscale * sqrt(2.0) * (4 + 1)) / 2.0;
+    return r < 1e9 ? (int)r : 1000000000;
+}
+
+// Largest radius the pipeline can produce: interval + offset_interval stays below intervals + 1.
+static int descr_max_radius(const sg_params &p)
+{
+    return descr_radius(p.sigma * pow(2.0, (p.intervals + 1.0) / p.intervals));
+}
+
+static void descr_phase(sg_ctx *c, const OctaveTab &tab, int B, int max_radius)
 {
     hipStream_t s = c->stream;
     unsigned int *n_feat = c->d_counts + 2 * c->B;
@@ -342,7 +355,7 @@ static void descr_phase(sg_ctx *c, const OctaveTab &tab, int B)
                            (size_t)c->feat_cap * kOriBins, c->d_frec, c->feat_cap, c->d_fscale, c->feat_cap,
                            c->feat_cap, B, s);
         launch_descr(tab, c->d_frec, c->feat_cap, n_feat, c->d_desc, (size_t)c->feat_cap * 128, c->d_pq,
-                     (size_t)c->feat_cap * 128, c->feat_cap, B, c->prm.precision, s);
+                     (size_t)c->feat_cap * 128, c->feat_cap, max_radius, B, c->prm.precision, s);
     }
 }
 
@@ -426,7 +439,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
     }
     detect_phase(c, c->tab, c->n_words, B, c->prm.nointerval);
     orient_phase(c, c->tab, B);
-    descr_phase(c, c->tab, B);
+    descr_phase(c, c->tab, B, descr_max_radius(c->prm));
     rank_phase(c, B);
     HIPCHK(c, hipGetLastError());
     return SG_OK;
@@ -1431,7 +1444,10 @@ int sg_descriptor_representation(sg_ctx *c, sg_keypoint *features, size_t n, con
     rc = upload_records(c, features, n, true);
     if (rc != SG_OK)
         return rc;
-    descr_phase(c, pyr.tab, 1);
+    int max_radius = 0;
+    for (size_t i = 0; i < n; i++)
+        max_radius = std::max(max_radius, descr_radius(features[i].octave_scale));
+    descr_phase(c, pyr.tab, 1, max_radius);
     rc = finish(c);
     if (rc != SG_OK || !n)
         return rc;

@@ -35,6 +35,7 @@ __device__ __forceinline__ void lds_add(double *p, double v)
 // [1/4 1/2 1/4] filter (sift.cpp:1209-1221), the maximum (sift.cpp:1231-1240) and the peak test with
 // parabolic refinement (sift.cpp:1280-1307) run on lanes 0..35.
 constexpr int kOriCopies = 4;
+constexpr int kOriCopyStride = 66; // doubles; 64 + 2, so that the copies start 4 banks apart
 constexpr int kOriPatch = 35; // window side + rim for radius <= 16 (the default parameters' maximum)
 
 // Same-wave LDS hand-off: LDS operations of one wave complete in order, so waiting for the wave's own
@@ -48,17 +49,20 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
                                                 unsigned long long *peak_words, size_t pw_img,
                                                 unsigned int *chunk_sums, size_t chunks_img, unsigned int cap)
 {
-    __shared__ double hist[4][kOriCopies][64];
+    __shared__ double hist[4][kOriCopies * kOriCopyStride];
     __shared__ double etab[4][64];
+    __shared__ double2 centres[5];
     __shared__ double patch_s[4][kOriPatch * kOriPatch];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     double *patch = patch_s[wave];
-    double *hs = hist[wave][0];
-    double *hc = hist[wave][lane & (kOriCopies - 1)];
+    double *hs = hist[wave];
+    double *hc = hist[wave] + (lane & (kOriCopies - 1)) * kOriCopyStride;
     double *E = etab[wave];
     const int b = blockIdx.y;
     const unsigned int n = min(kp_count[b], cap);
     const double PI2 = 2.0 * SG_PI;
+    sg_atan_centres_fill(centres, threadIdx.x, true);
+    __syncthreads();
 
     // every wave walks its own keypoints; nothing is shared between the waves of a block.  The slot index two
     // keypoints ahead and the record one keypoint ahead are loaded while the current keypoint is processed.
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
         const double econs = -1.0 / (2.0 * sig * sig);
 #pragma unroll
         for (int q = 0; q < kOriCopies; q++)
-            hist[wave][q][lane] = 0.0;
+            hist[wave][q * kOriCopyStride + lane] = 0.0;
         E[lane] = exp((lane * lane) * econs);
         wave_lds_fence();
         {
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
                 }
                 if (ok) {
                     double mag = sg_sqrt(dx * dx + dy * dy);
-                    double ori = sg_atan2(dy, dx);
+                    double ori = sg_atan2(dy, dx, centres);
                     double weight = use_tab ? E[abs(i)] * E[abs(jj)] : exp((i * i + jj * jj) * econs);
                     int bin = (int)rint(kOriBins * (SG_PI - ori) / PI2);
                     bin = bin < kOriBins ? bin : 0;
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
         const bool binlane = lane < kOriBins;
         double h0 = 0.0;
         if (binlane)
-            h0 = ((hist[wave][0][lane] + hist[wave][1][lane]) + hist[wave][2][lane]) + hist[wave][3][lane];
+            h0 = ((hs[lane] + hs[kOriCopyStride + lane]) + hs[2 * kOriCopyStride + lane]) + hs[3 * kOriCopyStride + lane];
         wave_lds_fence();
         if (binlane)
             hs[lane] = h0;
@@ -223,8 +227,8 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
 // Against the reference's per-sample formulas three things are algebraically regrouped (results agree to
 // ~1e-15 relative): the rotated coordinates use cos/shw and sin/shw in fused multiply-adds, the window weight
 // exp(-(rx^2+ry^2)/8), with rx^2+ry^2 = (i^2+j^2)/shw^2, is E[|i|]*E[|j|] from a per-feature table
-// E[k] = exp(-k^2/(8 shw^2)), and the angle wrap is one conditional add and subtract (its argument lies in
-// (-pi, 3pi]).  HistToDescriptor (sift.cpp:1567-1597): normalise, clamp at 0.2, normalise, min(255,(int)(512 v)).
+// E[k] = exp(-k^2/(8 shw^2)), and the orientation coordinate is formed directly in bin units and not wrapped
+// into [0, 8) (the bin index wraps).  HistToDescriptor (sift.cpp:1567-1597): normalise, clamp at 0.2, normalise, min(255,(int)(512 v)).
 
 constexpr int kDescQueue = 960;  // queue entries (samples) per round
 constexpr int kDescCopies = 4;
@@ -285,11 +289,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
     __shared__ double hist[kDescCopies * kDescCopyStride];
     __shared__ double etab[BIG ? kDescTab : kDescTabSmall];
     __shared__ unsigned short queue[kDescQueue];
+    __shared__ double2 centres[5];
     const int lane = threadIdx.x;
     const int b = blockIdx.y;
     const unsigned int n = min(feat_count[b], cap);
-    const double PI2 = SG_PI * 2;
     const FeatRec *fr = frec + (size_t)b * frec_img;
+    sg_atan_centres_fill(centres, lane, false);
 
     // the next feature's record is loaded while the current one is processed
     FeatRec nxt;
@@ -315,6 +320,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
         // window's first sample (that pixel itself may lie outside the image; it is never read).
         const T *g0 = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o] +
                       ((ptrdiff_t)(r.y - radius - 1) * pitch + (r.x - radius - 1));
+        const char *gb = reinterpret_cast<const char *>(g0);
+        const char *gb_up = reinterpret_cast<const char *>(g0 - pitch), *gb_dn = reinterpret_cast<const char *>(g0 + pitch);
+        const double obin_c = (SG_PI - ori) * (4.0 / SG_PI);
 
 #pragma unroll
         for (int q = 0; q < (kDescCopies * kDescCopyStride + 63) / 64; q++)
@@ -372,36 +380,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                 row++;
             }
             // ---- drain: double arithmetic on the listed samples ----
-            for (int e = lane; e < count; e += 64) {
-                unsigned int ri, ci; // row and column inside the window
+            // The sample list entry and the four neighbour pixels of the lane's next sample are fetched while the
+            // current sample is processed.
+            unsigned int rn = 0, cn = 0; // next sample's row and column inside the window
+            T nl = 0, nr = 0, nu = 0, nd = 0;
+            auto fetch = [&](int e) {
                 if (packed) {
                     const unsigned int pk = queue[e];
-                    ri = pk >> 8;
-                    ci = pk & 255u;
+                    rn = pk >> 8;
+                    cn = pk & 255u;
                 } else {
-                    ri = (unsigned int)big_row;
-                    ci = (unsigned int)(big_lo + e);
+                    rn = (unsigned int)big_row;
+                    cn = (unsigned int)(big_lo + e);
                 }
-                const int i = (int)ri - radius, jj = (int)ci - radius;
+                const unsigned int off = ((rn + 1u) * (unsigned int)pitch + (cn + 1u)) * (unsigned int)sizeof(T);
+                const char *p8 = gb + (size_t)off;
+                nl = *reinterpret_cast<const T *>(p8 - sizeof(T));
+                nr = *reinterpret_cast<const T *>(p8 + sizeof(T));
+                nu = *reinterpret_cast<const T *>(gb_up + (size_t)off);
+                nd = *reinterpret_cast<const T *>(gb_dn + (size_t)off);
+            };
+            if (lane < count)
+                fetch(lane);
+            for (int e = lane; e < count; e += 64) {
+                const int i = (int)rn - radius, jj = (int)cn - radius;
+                const double dx = (double)nr - (double)nl;
+                const double dy = (double)nd - (double)nu;
+                if (e + 64 < count)
+                    fetch(e + 64);
                 const double xbin = __builtin_fma(cs, (double)jj, __builtin_fma(-ss, (double)i, 1.5));
                 const double ybin = __builtin_fma(ss, (double)jj, __builtin_fma(cs, (double)i, 1.5));
                 if (xbin > -1.0 && xbin < 4 && ybin > -1.0 && ybin < 4) {
-                    const T *p = g0 + ((ri + 1u) * (unsigned int)pitch + (ci + 1u));
-                    double dx = (double)p[1] - (double)p[-1];
-                    double dy = (double)p[pitch] - (double)p[-pitch];
-                    double grad_mag = sg_sqrt(dx * dx + dy * dy);
-                    double grad_ori = (SG_PI - sg_atan2(dy, dx)) - ori;
-                    if (grad_ori < 0.0)
-                        grad_ori += PI2;
-                    if (grad_ori >= PI2)
-                        grad_ori -= PI2;
-                    double obin = grad_ori * (8 / PI2);
+                    const double grad_mag = sg_sqrt(dx * dx + dy * dy);
+                    // obin = ((pi - atan2(dy,dx)) - ori) * 8/(2 pi) = obin_c - atan2(dy,dx) in units of pi/4; the
+                    // histogram index below wraps by itself, so the angle is not brought into [0, 2 pi) first
+                    const double ax = fabs(dx), ay = fabs(dy);
+                    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+                    double kq;
+                    const double au = sg_atan_split(mn, mx, centres, kq);
+                    double q = __builtin_fma(au, 4.0 / SG_PI, kq);
+                    q = ay > ax ? 2.0 - q : q;
+                    q = dx < 0.0 ? 4.0 - q : q;
+                    const double obin = dy < 0.0 ? obin_c + q : obin_c - q;
                     double weight;
                     if (BIG && !packed)
                         weight = exp((i * i + jj * jj) * wcons);
                     else
                         weight = etab[abs(i)] * etab[abs(jj)];
-                    double mag = grad_mag * weight;
+                    const double mag = grad_mag * weight;
                     // InterpHistEntry
                     const double fr_ = floor(ybin), fc_ = floor(xbin), fo_ = floor(obin);
                     const int r0 = (int)fr_, c0 = (int)fc_, o0 = (int)fo_;

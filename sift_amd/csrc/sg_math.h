@@ -10,7 +10,17 @@
 
 namespace sg {
 
-// sqrt for 0 <= x in the normal range: v_rsq_f64 seed, two Newton-Raphson steps (Goldschmidt form).
+// a*b + c as one v_fma_f64 with three register operands.  (Left to itself the compiler turns a Horner step
+// "p*z + constant" into a register copy of the constant followed by the two-operand accumulate form.)
+__device__ __forceinline__ double sg_fma3(double a, double b, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
+// sqrt for 0 <= x in the normal range: v_rsq_f64 seed, one coupled Newton-Raphson step (Goldschmidt form)
+// and one residual correction; within 1 ulp.
 __device__ __forceinline__ double sg_sqrt(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
@@ -21,36 +31,73 @@ __device__ __forceinline__ double sg_sqrt(double x)
     h = __builtin_fma(h, r, h);
     double d = __builtin_fma(-g, g, x);
     g = __builtin_fma(d, h, g);
-    d = __builtin_fma(-g, g, x);
-    g = __builtin_fma(d, h, g);
     return x > 0.0 ? g : 0.0;
 }
 
-// atan2(y, x): octant folding to t = min/max in [0,1], then one of five centres c = tan(k*pi/16) with
-// u = (mn - c*mx) / (mx + c*mn), |u| <= tan(pi/32), so atan(t) = k*pi/16 + atan(u) with an 8-term odd
-// series (truncation < 5e-19).  One division in all.  atan2(0,0) = 0 like the C library.
-__device__ __forceinline__ double sg_atan2(double y, double x)
+// n / d for d > 0 in the normal range: v_rcp_f64 seed, one Newton step on the reciprocal and one residual
+// correction of the quotient (itself a Newton step); within 1 ulp.
+__device__ __forceinline__ double sg_div(double n, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    double q = n * r;
+    return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+
+// atan of a ratio mn/mx, 0 <= mn <= mx, split as  k*pi/16 + atan(u):  one of five centres c = tan(k*pi/16) is
+// chosen by comparing mn with mx*tan((2k-1)*pi/32), and u = (mn - c*mx) / (mx + c*mn) has |u| <= tan(pi/32), so an
+// 8-term odd series (truncation < 5e-19) gives atan(u).  One division in all; mn = mx = 0 gives k = 0, u = 0.
+// `centres` is a 5-entry table of (c, caller's multiple of k) pairs, normally in LDS (sg_atan_centres_fill).
+__device__ __forceinline__ double sg_atan_split(double mn, double mx, const double2 *centres, double &k_term)
+{
+    int k = (mn > 0.09849140335716425 * mx ? 1 : 0) + (mn > 0.30334668360734239 * mx ? 1 : 0) +
+            (mn > 0.53451113595079158 * mx ? 1 : 0) + (mn > 0.82067879082866024 * mx ? 1 : 0);
+    const double2 ck = centres[k];
+    k_term = ck.y;
+    const double num = __builtin_fma(-ck.x, mx, mn);
+    const double den = fmax(__builtin_fma(ck.x, mn, mx), 1e-300);
+    const double u = sg_div(num, den);
+    const double z = u * u;
+    double p = -1.0 / 15.0;
+    p = sg_fma3(p, z, 1.0 / 13.0);
+    p = sg_fma3(p, z, -1.0 / 11.0);
+    p = sg_fma3(p, z, 1.0 / 9.0);
+    p = sg_fma3(p, z, -1.0 / 7.0);
+    p = sg_fma3(p, z, 1.0 / 5.0);
+    p = sg_fma3(p, z, -1.0 / 3.0);
+    return __builtin_fma(u * z, p, u);
+}
+
+// centres[k] = (tan(k*pi/16), k*pi/16) if radians, else (tan(k*pi/16), k/4) -- the angle in units of pi/4 -- for
+// k = 0..4; call with lanes 0..4 at least, then make the stores visible to the readers.
+__device__ __forceinline__ void sg_atan_centres_fill(double2 *centres, int lane, bool radians)
+{
+    if (lane < 5) {
+        double2 e;
+        e.x = lane == 0 ? 0.0
+            : lane == 1 ? 0.19891236737965800
+            : lane == 2 ? 0.41421356237309503
+            : lane == 3 ? 0.66817863791929888
+                        : 1.0;
+        const double rad = lane == 0 ? 0.0
+                         : lane == 1 ? 0.19634954084936207
+                         : lane == 2 ? 0.39269908169872414
+                         : lane == 3 ? 0.58904862254808621
+                                     : 0.78539816339744828;
+        e.y = radians ? rad : 0.25 * lane;
+        centres[lane] = e;
+    }
+}
+
+// atan2(y, x) in radians; centres filled with radians = true.  atan2(0,0) = 0 like the C library.
+__device__ __forceinline__ double sg_atan2(double y, double x, const double2 *centres)
 {
     const double ax = fabs(x), ay = fabs(y);
     const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
-    // interval boundaries tan((2k+1)*pi/32), centres tan(k*pi/16), offsets k*pi/16
-    double c = 0.0, off = 0.0;
-    if (mn > 0.09849140335716425 * mx) { c = 0.19891236737965800; off = 0.19634954084936207; }
-    if (mn > 0.30334668360734239 * mx) { c = 0.41421356237309503; off = 0.39269908169872414; }
-    if (mn > 0.53451113595079158 * mx) { c = 0.66817863791929888; off = 0.58904862254808621; }
-    if (mn > 0.82067879082866024 * mx) { c = 1.0; off = 0.78539816339744828; }
-    const double num = __builtin_fma(-c, mx, mn);
-    const double den = __builtin_fma(c, mn, mx);
-    const double u = den > 0.0 ? num / den : 0.0;
-    const double z = u * u;
-    double p = -1.0 / 15.0;
-    p = __builtin_fma(p, z, 1.0 / 13.0);
-    p = __builtin_fma(p, z, -1.0 / 11.0);
-    p = __builtin_fma(p, z, 1.0 / 9.0);
-    p = __builtin_fma(p, z, -1.0 / 7.0);
-    p = __builtin_fma(p, z, 1.0 / 5.0);
-    p = __builtin_fma(p, z, -1.0 / 3.0);
-    double r = off + __builtin_fma(u * z, p, u);
+    double off;
+    const double a = sg_atan_split(mn, mx, centres, off);
+    double r = off + a;
     if (ay > ax)
         r = 1.5707963267948966 - r;
     if (x < 0.0)

@@ -26,48 +26,50 @@ __device__ __forceinline__ void lds_add(double *p, double v)
 }
 
 // ---- orientation ---------------------------------------------------------------------------------------
-// One wave per keypoint.  CalculateOrientationHistogram (sift.cpp:1149-1199): the lanes walk the
-// (2r+1)^2 window and add mag*weight into wave-private 36-bin LDS histograms with double atomics.  Each
-// wave keeps four copies (lane & 3) so that neighbouring lanes, whose gradients point the same way, do
-// not serialise on one bin; copies are added in a fixed order, and one wave's adds to one copy resolve
-// in a fixed order, so sums are reproducible run to run.  The Gaussian weight exp(-(i^2+j^2)/(2 s^2)) is
-// taken as E[|i|]*E[|j|] from a per-keypoint table of E[k] = exp(-k^2/(2 s^2)).  Two passes of the circular
-// [1/4 1/2 1/4] filter (sift.cpp:1209-1221), the maximum (sift.cpp:1231-1240) and the peak test with
-// parabolic refinement (sift.cpp:1280-1307) run on lanes 0..35.
+// One wave (a 64-thread workgroup) per keypoint.  CalculateOrientationHistogram (sift.cpp:1149-1199): the
+// lanes walk the (2r+1)^2 window and add mag*weight into 36-bin LDS histograms with double atomics.  The
+// wave keeps four copies (lane & 3, at a stride that puts them in different banks) so that neighbouring
+// lanes, whose gradients point the same way, do not serialise on one bin; copies are added in a fixed order,
+// and one wave's adds to one copy resolve in a fixed order, so sums are reproducible run to run.  The four
+// neighbour pixels of a lane's next sample are fetched while the current one is processed.  The Gaussian
+// weight exp(-(i^2+j^2)/(2 s^2)) is taken as E[|i|]*E[|j|] from a per-keypoint table of
+// E[k] = exp(-k^2/(2 s^2)).  Two passes of the circular [1/4 1/2 1/4] filter (sift.cpp:1209-1221), the
+// maximum (sift.cpp:1231-1240) and the peak test with parabolic refinement (sift.cpp:1280-1307) run on
+// lanes 0..35.  BIG (chosen on the host from the largest radius the parameters allow) adds the path for
+// windows of radius 64 and more, whose weights do not fit the table.
 constexpr int kOriCopies = 4;
 constexpr int kOriCopyStride = 66; // doubles; 64 + 2, so that the copies start 4 banks apart
-constexpr int kOriPatch = 35; // window side + rim for radius <= 16 (the default parameters' maximum)
+constexpr int kOriTab = 64;
 
 // Same-wave LDS hand-off: LDS operations of one wave complete in order, so waiting for the wave's own
 // outstanding LDS operations makes earlier stores and atomics visible to its later loads (other lanes included).
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <typename T>
-__global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, size_t kp_img,
-                                                const unsigned int *kp_src, size_t src_img,
-                                                const unsigned int *kp_count, double *ori_tmp, size_t ori_img,
-                                                unsigned long long *peak_words, size_t pw_img,
-                                                unsigned int *chunk_sums, size_t chunks_img, unsigned int cap)
+#ifndef SG_ORI_WPE
+#define SG_ORI_WPE 5
+#endif
+template <typename T, bool BIG>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_ORI_WPE, SG_ORI_WPE))) void
+orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsigned int *__restrict__ kp_src,
+         size_t src_img, const unsigned int *__restrict__ kp_count, double *__restrict__ ori_tmp, size_t ori_img,
+         unsigned long long *__restrict__ peak_words, size_t pw_img, unsigned int *__restrict__ chunk_sums,
+         size_t chunks_img, unsigned int cap)
 {
-    __shared__ double hist[4][kOriCopies * kOriCopyStride];
-    __shared__ double etab[4][64];
+    __shared__ double hist[kOriCopies * kOriCopyStride];
+    __shared__ double E[kOriTab];
     __shared__ double2 centres[5];
-    __shared__ double patch_s[4][kOriPatch * kOriPatch];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    double *patch = patch_s[wave];
-    double *hs = hist[wave];
-    double *hc = hist[wave] + (lane & (kOriCopies - 1)) * kOriCopyStride;
-    double *E = etab[wave];
+    const int lane = threadIdx.x;
+    double *hs = hist;
+    double *hc = hist + (lane & (kOriCopies - 1)) * kOriCopyStride;
     const int b = blockIdx.y;
     const unsigned int n = min(kp_count[b], cap);
     const double PI2 = 2.0 * SG_PI;
-    sg_atan_centres_fill(centres, threadIdx.x, true);
-    __syncthreads();
+    sg_atan_centres_fill(centres, lane, true);
 
-    // every wave walks its own keypoints; nothing is shared between the waves of a block.  The slot index two
-    // keypoints ahead and the record one keypoint ahead are loaded while the current keypoint is processed.
-    const unsigned int jstep = gridDim.x * 4u;
-    const unsigned int j_first = blockIdx.x * 4u + wave;
+    // The slot index two keypoints ahead and the record one keypoint ahead are loaded while the current
+    // keypoint is processed.
+    const unsigned int jstep = gridDim.x;
+    const unsigned int j_first = blockIdx.x;
     const unsigned int *ks = kp_src + (size_t)b * src_img;
     const KpRec *kpb = kp + (size_t)b * kp_img;
     KpRec rec_next;
@@ -87,64 +89,64 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
         const double econs = -1.0 / (2.0 * sig * sig);
 #pragma unroll
         for (int q = 0; q < kOriCopies; q++)
-            hist[wave][q * kOriCopyStride + lane] = 0.0;
+            hist[q * kOriCopyStride + lane] = 0.0;
         E[lane] = exp((lane * lane) * econs);
         wave_lds_fence();
         {
             const int o = r.octave;
-            const T *g = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o];
             const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
+            const char *gb = reinterpret_cast<const char *>((const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o]);
+            const unsigned int pitch_b = (unsigned int)pitch * (unsigned int)sizeof(T);
             const int W = 2 * radius + 1, total = W * W;
-            const bool use_tab = radius < 64;
-            // The window plus a one-pixel rim is staged in LDS first (all loads in flight at once, clamped at
-            // the image border; validity is still decided from the coordinates), unless it exceeds the patch.
-            const int S = W + 2;
-            const bool use_patch = S <= kOriPatch;
-            if (use_patch) {
-                const int px0 = r.x - radius - 1, py0 = r.y - radius - 1;
-                int ey = lane / S, ex = lane - ey * S;
-                const int edq = 64 / S, edr = 64 - edq * S;
-                for (int e = lane; e < S * S; e += 64) {
-                    int yy = min(max(py0 + ey, 0), rows - 1), xx = min(max(px0 + ex, 0), cols - 1);
-                    patch[e] = (double)g[(size_t)yy * pitch + xx];
-                    ey += edq;
-                    ex += edr;
-                    if (ex >= S) {
-                        ex -= S;
-                        ey++;
-                    }
-                }
-                wave_lds_fence();
-            }
-            // sample s -> (i = s / W - radius: x offset, the reference's outer loop; jj = s % W - radius: y offset)
-            int qi = lane / W, qj = lane - qi * W;
+            const bool use_tab = !BIG || radius < kOriTab;
+            // sample s -> (jj = s / W - radius: y offset; i = s % W - radius: x offset), so that neighbouring lanes
+            // read neighbouring pixels (the reference walks x in its outer loop; the sums do not depend on it
+            // beyond rounding)
+            int qj = lane / W, qi = lane - qj * W;
             const int dq = 64 / W, dr = 64 - dq * W;
-            for (int s = lane; s < total; s += 64) {
-                const int i = qi - radius, jj = qj - radius;
-                double dx, dy;
-                bool ok;
-                if (use_patch) {
-                    const int x = r.x + i, y = r.y + jj;
-                    ok = x > 0 && x < cols - 1 && y > 0 && y < rows - 1;
-                    const double *pp = patch + (qj + 1) * S + (qi + 1);
-                    dx = pp[1] - pp[-1];
-                    dy = pp[S] - pp[-S];
-                } else {
-                    ok = grad_at(g, rows, cols, pitch, r.x + i, r.y + jj, dx, dy);
+            int i_n = 0, j_n = 0;
+            bool ok_n = false;
+            T nl = 0, nr = 0, nu = 0, nd = 0;
+            auto fetch = [&]() {
+                i_n = qi - radius;
+                j_n = qj - radius;
+                const int x = r.x + i_n, y = r.y + j_n;
+                ok_n = x > 0 && x < cols - 1 && y > 0 && y < rows - 1; // CalcGradMagOri's validity (sift.cpp:1115)
+                // the loads of an invalid sample are redirected to the nearest pixel that has four neighbours
+                const int xx = min(max(x, 1), cols - 2), yy = min(max(y, 1), rows - 2);
+                const unsigned int off = (unsigned int)yy * pitch_b + (unsigned int)xx * (unsigned int)sizeof(T);
+                const char *p8 = gb + (size_t)off;
+                nl = *reinterpret_cast<const T *>(p8 - sizeof(T));
+                nr = *reinterpret_cast<const T *>(p8 + sizeof(T));
+                nu = *reinterpret_cast<const T *>(p8 - (size_t)pitch_b);
+                nd = *reinterpret_cast<const T *>(p8 + (size_t)pitch_b);
+                qj += dq;
+                qi += dr;
+                if (qi >= W) {
+                    qi -= W;
+                    qj++;
                 }
+            };
+            if (lane < total)
+                fetch();
+            for (int s = lane; s < total; s += 64) {
+                const int i = i_n, jj = j_n;
+                const bool ok = ok_n;
+                const double dx = (double)nr - (double)nl;
+                const double dy = (double)nd - (double)nu;
+                if (s + 64 < total)
+                    fetch();
                 if (ok) {
                     double mag = sg_sqrt(dx * dx + dy * dy);
                     double ori = sg_atan2(dy, dx, centres);
-                    double weight = use_tab ? E[abs(i)] * E[abs(jj)] : exp((i * i + jj * jj) * econs);
+                    double weight;
+                    if (use_tab)
+                        weight = E[abs(i)] * E[abs(jj)];
+                    else
+                        weight = exp((i * i + jj * jj) * econs);
                     int bin = (int)rint(kOriBins * (SG_PI - ori) / PI2);
                     bin = bin < kOriBins ? bin : 0;
                     lds_add(&hc[bin], mag * weight);
-                }
-                qi += dq;
-                qj += dr;
-                if (qj >= W) {
-                    qj -= W;
-                    qi++;
                 }
             }
         }
@@ -201,18 +203,28 @@ __global__ __launch_bounds__(256) void orient_k(OctaveTab tab, const KpRec *kp, 
 void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
                    size_t src_img_stride, const unsigned int *kp_count, double *ori_tmp, size_t ori_img_stride,
                    unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
-                   size_t chunks_img_stride, unsigned int cap, int B, int prec, hipStream_t s)
+                   size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec, hipStream_t s)
 {
-    unsigned int blocks = (cap + 3) / 4;
-    if (blocks > 4096)
-        blocks = 4096;
+    unsigned int blocks = cap < 16384 ? cap : 16384;
+    if (blocks == 0)
+        return;
     dim3 g(blocks, B);
-    if (prec == SG_F64)
-        orient_k<double><<<g, 256, 0, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, kp_count, ori_tmp,
-                                           ori_img_stride, peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap);
-    else
-        orient_k<float><<<g, 256, 0, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, kp_count, ori_tmp,
-                                          ori_img_stride, peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap);
+    const bool big = max_radius >= kOriTab;
+#define SG_ORI_LAUNCH(TT, BB)                                                                                         \
+    orient_k<TT, BB><<<g, 64, 0, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, kp_count, ori_tmp, ori_img_stride, \
+                                      peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap)
+    if (prec == SG_F64) {
+        if (big)
+            SG_ORI_LAUNCH(double, true);
+        else
+            SG_ORI_LAUNCH(double, false);
+    } else {
+        if (big)
+            SG_ORI_LAUNCH(float, true);
+        else
+            SG_ORI_LAUNCH(float, false);
+    }
+#undef SG_ORI_LAUNCH
 }
 
 // ---- descriptors -----------------------------------------------------------------------------------------

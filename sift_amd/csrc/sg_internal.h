@@ -99,7 +99,7 @@ void launch_refine(const OctaveTab &tab, const unsigned int *cand, size_t cand_i
 void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
                    size_t src_img_stride, const unsigned int *kp_count, double *ori_tmp, size_t ori_img_stride,
                    unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
-                   size_t chunks_img_stride, unsigned int cap, int B, int prec, hipStream_t s);
+                   size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec, hipStream_t s);
 // gathers FeatRec[f] (and fscale[f]) from feat_src -> kp_src -> kp / ori_tmp
 void launch_feat_gather(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src, size_t src_img_stride,
                         const unsigned int *feat_src, size_t fsrc_img_stride, const unsigned int *feat_count,

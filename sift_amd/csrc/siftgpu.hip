@@ -313,7 +313,7 @@ static void detect_phase(sg_ctx *c, const OctaveTab &tab, unsigned int n_words, 
     }
 }
 
-static void orient_phase(sg_ctx *c, const OctaveTab &tab, int B)
+static void orient_phase(sg_ctx *c, const OctaveTab &tab, int B, int max_radius)
 {
     hipStream_t s = c->stream;
     unsigned int *ch3 = c->d_chunks + c->chunks1 + c->chunks2;
@@ -321,7 +321,7 @@ static void orient_phase(sg_ctx *c, const OctaveTab &tab, int B)
     {
         StageScope sc(c, SG_ST_ORIENT);
         launch_orient(tab, c->d_kp, c->cand_cap, c->d_kpsrc, c->feat_cap, n_kp, c->d_ori, (size_t)c->feat_cap * kOriBins,
-                      c->d_pwords, c->pwords_img, ch3, c->chunks_total, c->feat_cap, B, c->prm.precision, s);
+                      c->d_pwords, c->pwords_img, ch3, c->chunks_total, c->feat_cap, max_radius, B, c->prm.precision, s);
     }
     {
         StageScope sc(c, SG_ST_COMPACT, 2);
@@ -339,10 +339,22 @@ static int descr_radius(double oscale)
     return r < 1e9 ? (int)r : 1000000000;
 }
 
-// Largest radius the pipeline can produce: interval + offset_interval stays below intervals + 1.
+// Orientation window radius (reference sift/sift.cpp:1326).
+static int ori_radius(double oscale)
+{
+    const double r = 3.0 * 1.5 * oscale;
+    return r < 1e9 ? (int)rint(r) : 1000000000;
+}
+
+// Largest radii the pipeline can produce: interval + offset_interval stays below intervals + 1.
 static int descr_max_radius(const sg_params &p)
 {
     return descr_radius(p.sigma * pow(2.0, (p.intervals + 1.0) / p.intervals));
+}
+
+static int ori_max_radius(const sg_params &p)
+{
+    return ori_radius(p.sigma * pow(2.0, (p.intervals + 1.0) / p.intervals));
 }
 
 static void descr_phase(sg_ctx *c, const OctaveTab &tab, int B, int max_radius)
@@ -438,7 +450,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
             blur_planes(c, c->level[o][l - 1], c->level[o][l], B, c->taps[l], c->ntaps[l], l);
     }
     detect_phase(c, c->tab, c->n_words, B, c->prm.nointerval);
-    orient_phase(c, c->tab, B);
+    orient_phase(c, c->tab, B, ori_max_radius(c->prm));
     descr_phase(c, c->tab, B, descr_max_radius(c->prm));
     rank_phase(c, B);
     HIPCHK(c, hipGetLastError());
@@ -1406,7 +1418,10 @@ int sg_orientation_assignment(sg_ctx *c, const sg_keypoint *extrema, size_t n_ex
         return rc;
     (void)hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int) * 4, c->stream);
     (void)hipMemsetAsync(c->d_chunks + c->chunks1 + c->chunks2, 0, sizeof(unsigned int) * c->chunks3, c->stream);
-    orient_phase(c, pyr.tab, 1);
+    int max_radius = 0;
+    for (size_t i = 0; i < n_extrema; i++)
+        max_radius = std::max(max_radius, ori_radius(extrema[i].octave_scale));
+    orient_phase(c, pyr.tab, 1, max_radius);
     rc = check_overflow(c);
     if (rc != SG_OK)
         return rc;

@@ -28,7 +28,8 @@ __device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf
 
 // ---- fused DoG + extrema scan ----------------------------------------------------------------------
 // One wave owns a 64-pixel segment of RS consecutive rows and all three scanned layers.  Each lane
-// keeps, for the 5 DoG levels, a 3-row x 3-column window in registers and slides it down the rows.
+// keeps, for the 5 DoG levels, the extremes of a 3-row x 3-column window as running column/row partial
+// maxima and minima and slides them down the rows.
 // isExtremum (reference sift/sift.cpp:473-526): val > 0 -> no neighbour (27 incl. centre) greater;
 // otherwise no neighbour smaller.  Pre-threshold |val| > thresh is strict (sift.cpp:945).
 template <typename T, bool FROM_DOG, bool NOINT, int RS>
@@ -54,14 +55,20 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
     unsigned long long *wbase = words + (size_t)b * words_img + tab.wbase[o];
     unsigned int *csum = chunk_sums + (size_t)b * chunks_img;
 
-    T d[3][kDogLevels][3]; // [row slot][dog level][column x-1..x+1]
-    auto load_row = [&](int slot, int y) {
+    // Per DoG level the lane keeps the maximum and minimum over columns x-1..x+1 of the current row (rmx1, rmn1)
+    // and of the current and previous rows together (rmx01, rmn01); with the next row's column extremes the
+    // 3x3 extremes of a level cost two operations each per row.  cen1 / cen2: the centre values of the three
+    // scanned layers in the current and next row.
+    T rmx01[kDogLevels], rmn01[kDogLevels], rmx1[kDogLevels], rmn1[kDogLevels], rmx2[kDogLevels], rmn2[kDogLevels];
+    T cen1[3], cen2[3];
+    auto load_row = [&](int y) { // fills rmx2 / rmn2 / cen2 from row y
         size_t off = img + (size_t)y * pitch + xc;
+        T d[kDogLevels][3];
         if (FROM_DOG) {
 #pragma unroll
             for (int l = 0; l < kDogLevels; l++) {
                 const T *p = (const T *)tab.lv[o][l] + off;
-                d[slot][l][0] = p[-1]; d[slot][l][1] = p[0]; d[slot][l][2] = p[1];
+                d[l][0] = p[-1]; d[l][1] = p[0]; d[l][2] = p[1];
             }
         } else {
             T g[kLevels][3];
@@ -74,37 +81,52 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
             for (int l = 0; l < kDogLevels; l++) {
 #pragma unroll
                 for (int c = 0; c < 3; c++)
-                    d[slot][l][c] = g[l + 1][c] - g[l][c];
+                    d[l][c] = g[l + 1][c] - g[l][c];
             }
         }
+#pragma unroll
+        for (int l = 0; l < kDogLevels; l++) {
+            rmx2[l] = vmax(vmax(d[l][0], d[l][1]), d[l][2]);
+            rmn2[l] = vmin(vmin(d[l][0], d[l][1]), d[l][2]);
+        }
+#pragma unroll
+        for (int l = 0; l < 3; l++)
+            cen2[l] = d[l + 1][1];
     };
 
     unsigned int n00 = 0, n0 = 0, n1 = 0;
     if (y_begin < y_end) {
-        load_row(0, y_begin - 1);
-        load_row(1, y_begin);
+        load_row(y_begin - 1);
+#pragma unroll
+        for (int l = 0; l < kDogLevels; l++) {
+            rmx1[l] = rmx2[l];
+            rmn1[l] = rmn2[l];
+        }
+        load_row(y_begin);
+#pragma unroll
+        for (int l = 0; l < kDogLevels; l++) {
+            rmx01[l] = vmax(rmx1[l], rmx2[l]);
+            rmn01[l] = vmin(rmn1[l], rmn2[l]);
+            rmx1[l] = rmx2[l];
+            rmn1[l] = rmn2[l];
+        }
+#pragma unroll
+        for (int l = 0; l < 3; l++)
+            cen1[l] = cen2[l];
     }
     for (int y = y_begin; y < y_end; y++) {
-        load_row(2, y + 1);
+        load_row(y + 1);
         // per-level 3x3 max and min
         T mx[kDogLevels], mn[kDogLevels];
 #pragma unroll
         for (int l = 0; l < kDogLevels; l++) {
-            T a = d[0][l][0], i = a;
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    a = vmax(a, d[r][l][c]);
-                    i = vmin(i, d[r][l][c]);
-                }
-            }
-            mx[l] = a; mn[l] = i;
+            mx[l] = vmax(rmx01[l], rmx2[l]);
+            mn[l] = vmin(rmn01[l], rmn2[l]);
         }
         n00 += __popcll(__ballot(x_ok));
 #pragma unroll
         for (int layer = 1; layer <= 3; layer++) {
-            T val = d[1][layer][1];
+            T val = cen1[layer - 1];
             bool pre = x_ok && (fabs((double)val) > thresh);
             T hi = mx[layer], lo = mn[layer];
             if (!NOINT) {
@@ -123,15 +145,17 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
                     atomicAdd(&csum[(tab.wbase[o] + widx) / kChunkWords], (unsigned int)__popcll(mext));
             }
         }
-        // slide the window down one row
+        // slide down one row
 #pragma unroll
         for (int l = 0; l < kDogLevels; l++) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                d[0][l][c] = d[1][l][c];
-                d[1][l][c] = d[2][l][c];
-            }
+            rmx01[l] = vmax(rmx1[l], rmx2[l]);
+            rmn01[l] = vmin(rmn1[l], rmn2[l]);
+            rmx1[l] = rmx2[l];
+            rmn1[l] = rmn2[l];
         }
+#pragma unroll
+        for (int l = 0; l < 3; l++)
+            cen1[l] = cen2[l];
     }
     // counters: one LDS add per wave, then one global add per block and counter
     if (lane == 0 && n00) {

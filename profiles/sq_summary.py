@@ -8,6 +8,7 @@ import sys
 from collections import defaultdict
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+write = tag != "tmp"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 
@@ -36,6 +37,8 @@ for p in ("sq_a", "sq_b"):
 txt = "\n".join(out)
 print(txt)
 dst = os.path.join(root, "profiles", tag)
-os.makedirs(dst, exist_ok=True)
-open(os.path.join(dst, "sq_counters.md"), "w").write(
+if write:
+    os.makedirs(dst, exist_ok=True)
+if write:
+    open(os.path.join(dst, "sq_counters.md"), "w").write(
     "# SQ counter sums per kernel over two steps (warm-up + timed) of `python bench.py --steps 1 --warmup 1`\n\n" + txt + "\n")

@@ -11,6 +11,9 @@
 // Both passes are HBM-bound streaming kernels: 16-byte accesses per lane, halos staged in LDS.
 #include "sg_internal.h"
 
+#include <stdlib.h>
+#include <string.h>
+
 namespace sg {
 
 // BORDER_REFLECT_101, repeated until in range (planes narrower than the kernel occur in the
@@ -22,6 +25,15 @@ __device__ __forceinline__ int reflect101(int p, int len)
     while (p < 0 || p >= len)
         p = p < 0 ? -p : 2 * (len - 1) - p;
     return p;
+}
+
+// BORDER_REFLECT_101 for indices at most len-1 outside [0, len) (one reflection), clamped for anything
+// further out (only reached by lanes whose results are masked).  Branch-free.
+__device__ __forceinline__ int reflect101_once(int p, int len)
+{
+    p = p < 0 ? -p : p;
+    p = p >= len ? 2 * (len - 1) - p : p;
+    return min(max(p, 0), len - 1);
 }
 
 template <typename T, int V>
@@ -370,6 +382,185 @@ static size_t fused_lds_bytes()
     return sizeof(T) * ((size_t)RING * TW + (size_t)4 * KR * RAWW);
 }
 
+// ---- fused row + column pass, column window in registers ------------------------------------------------
+// Every wave is on its own: it owns a strip of TW = 64*V columns and walks down a segment of rows.  An input
+// row is read from HBM once (16 bytes per lane plus the 2R halo columns), row-filtered through a wave-private
+// LDS image of the raw row, and the row-filtered vector enters a window of the last 2R+KR rows that the lane
+// holds in registers; the column filter is evaluated on the window.  KR input rows are taken per iteration,
+// so that the window is shifted by KR register moves per KR rows; the loads of the next iteration are in
+// flight during the arithmetic.  No workgroup barrier, no LDS traffic for the column pass.  Arithmetic and
+// operation order per pixel are those of the two-pass kernels above, so results are bit-identical to them;
+// HBM traffic is one read and one write per pixel (plus 2R re-read rows per segment).
+#ifndef SG_WIN_WPE13
+#define SG_WIN_WPE13 2
+#endif
+#ifndef SG_WIN_WPE10
+#define SG_WIN_WPE10 3
+#endif
+#ifndef SG_WIN_WPE8
+#define SG_WIN_WPE8 3
+#endif
+#ifndef SG_WIN_WPE6
+#define SG_WIN_WPE6 4
+#endif
+// resident waves per SIMD the register allocation of each radius aims at
+constexpr int win_waves_per_simd(int R) { return R <= 6 ? SG_WIN_WPE6 : (R <= 8 ? SG_WIN_WPE8 : (R <= 10 ? SG_WIN_WPE10 : SG_WIN_WPE13)); }
+
+template <typename T, int R, int V>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(win_waves_per_simd(R), win_waves_per_simd(R))))
+void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols,
+                                                  int spitch, int dpitch, size_t simg, size_t dimg, int seg,
+                                                  Taps<T> taps)
+{
+    typedef typename VecOf<T, V>::type vec_t;
+    constexpr int TW = 64 * V;
+    constexpr int KR = 2;                              // input rows per iteration
+    constexpr int WIN = 2 * R + KR;                    // rows in the register window
+    constexpr int NWIN = (V + 2 * R + V - 1) / V;      // vectors per row window
+    constexpr int RAWW = (R + TW + NWIN * V + 3) & ~3; // raw row image incl. read overshoot, 16-byte rows
+    static_assert((2 * R) % KR == 0, "the first complete window must end on an iteration boundary");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    T *raw = reinterpret_cast<T *>(smem_raw) + (size_t)wave * KR * RAWW;
+    const int x0 = blockIdx.x * TW;
+    const int ys = (blockIdx.y * 4 + wave) * seg;
+    if (ys >= rows)
+        return; // the whole wave; there is no barrier in this kernel
+    const int ye = min(ys + seg, rows);
+    const int xb = x0 + lane * V;
+    const T *s = src + blockIdx.z * simg;
+    T *d = dst + blockIdx.z * dimg;
+    const int n_iter = (ye - ys + 2 * R + KR - 1) / KR;
+    const bool strip_full = x0 + TW <= cols; // wave-uniform: every lane's vector lies inside the row
+    const int hx = lane < R ? x0 - R + lane : x0 + TW + (lane - R); // halo column of this lane (lanes < 2R)
+    const int hxr = reflect101_once(hx, cols);
+    int xe[V]; // element columns for the strip that crosses the right border
+#pragma unroll
+    for (int q = 0; q < V; q++)
+        xe[q] = reflect101_once(xb + q, cols);
+
+    vec_t mainv[KR];
+    T halo[KR];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const int yy = reflect101_once(ys - R + KR * t + k, rows);
+            const T *sr = s + (size_t)yy * spitch;
+            if (strip_full) {
+                mainv[k] = *reinterpret_cast<const vec_t *>(sr + xb);
+            } else {
+                T *pv = reinterpret_cast<T *>(&mainv[k]);
+#pragma unroll
+                for (int q = 0; q < V; q++)
+                    pv[q] = sr[xe[q]];
+            }
+            halo[k] = sr[hxr]; // lanes >= 2R load a valid (unused) pixel
+        }
+    };
+
+    vec_t win[WIN];
+#pragma unroll
+    for (int j = 0; j < WIN; j++) {
+        T *pw = reinterpret_cast<T *>(&win[j]);
+#pragma unroll
+        for (int e = 0; e < V; e++)
+            pw[e] = (T)0;
+    }
+    fetch(0);
+    for (int t = 0; t < n_iter; t++) {
+#pragma unroll
+        for (int j = 0; j + KR < WIN; j++)
+            win[j] = win[j + KR];
+        // ---- row pass: KR input rows through the raw image ----
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            // element stores: the image starts R columns left of the strip, so this address is 16-byte
+            // aligned only when R is a multiple of V; the window reads below are the aligned side
+            const T *pm = reinterpret_cast<const T *>(&mainv[k]);
+#pragma unroll
+            for (int q = 0; q < V; q++)
+                raw[k * RAWW + R + lane * V + q] = pm[q];
+            if (lane < 2 * R)
+                raw[k * RAWW + (lane < R ? lane : TW + lane)] = halo[k];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // same-wave LDS hand-off between lanes
+        if (t + 1 < n_iter)
+            fetch(t + 1);
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            vec_t o;
+            T *po = reinterpret_cast<T *>(&o);
+            // all window reads of the row are issued before the arithmetic starts
+            vec_t rv[NWIN];
+#pragma unroll
+            for (int q = 0; q < NWIN; q++)
+                rv[q] = *reinterpret_cast<const vec_t *>(raw + k * RAWW + lane * V + q * V);
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int q = 0; q < NWIN; q++) {
+                const vec_t v = rv[q];
+                const T *pv = reinterpret_cast<const T *>(&v);
+                // window element index e = q*V + j feeds output vo with tap tt = e - vo
+#pragma unroll
+                for (int j = 0; j < V; j++) {
+                    const int e = q * V + j;
+#pragma unroll
+                    for (int vo = 0; vo < V; vo++) {
+                        const int tt = e - vo;
+                        if (tt == 0)
+                            po[vo] = taps.k[0] * pv[j];
+                        else if (tt > 0 && tt <= 2 * R)
+                            po[vo] += taps.k[tt] * pv[j];
+                    }
+                }
+            }
+            win[2 * R + k] = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the raw image is overwritten next
+        // ---- column pass: output rows n0 .. n0+KR-1 (segment-relative) from window rows k .. k+2R ----
+        const int n0 = KR * t - 2 * R;
+        if (n0 >= 0 && xb < cols) {
+#pragma unroll
+            for (int k = 0; k < KR; k++) {
+                vec_t acc;
+                T *pa = reinterpret_cast<T *>(&acc);
+                const T *pc = reinterpret_cast<const T *>(&win[R + k]);
+#pragma unroll
+                for (int e = 0; e < V; e++)
+                    pa[e] = taps.k[R] * pc[e];
+#pragma unroll
+                for (int tt = 1; tt <= R; tt++) {
+                    const T *pu = reinterpret_cast<const T *>(&win[R + k + tt]);
+                    const T *pd = reinterpret_cast<const T *>(&win[R + k - tt]);
+#pragma unroll
+                    for (int e = 0; e < V; e++)
+                        pa[e] += taps.k[R + tt] * (pu[e] + pd[e]);
+                }
+                const int y = ys + n0 + k;
+                if (y < ye) {
+                    T *dr = d + (size_t)y * dpitch;
+                    if (strip_full) {
+                        *reinterpret_cast<vec_t *>(dr + xb) = acc;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < V; e++)
+                            if (xb + e < cols)
+                                dr[xb + e] = pa[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <typename T, int R, int V>
+static size_t win_lds_bytes()
+{
+    constexpr int TW = 64 * V, KR = 2;
+    constexpr int NWIN = (V + 2 * R + V - 1) / V, RAWW = (R + TW + NWIN * V + 3) & ~3;
+    return sizeof(T) * (size_t)4 * KR * RAWW;
+}
+
 // ---- any-radius fallback (one thread per output pixel, taps in global memory) ------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void blur_row_any_k(const T *src, T *dst, int rows, int cols, int spitch,
@@ -525,6 +716,15 @@ static void col_dispatch(const Plane &src, const Plane &dst, int B, const double
 #undef SG_COL_CASE
 }
 
+static bool blur_use_ring()
+{
+    static const bool v = [] {
+        const char *e = getenv("SIFTGPU_BLUR");
+        return e && strcmp(e, "ring") == 0;
+    }();
+    return v;
+}
+
 template <typename T, int V>
 static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s)
 {
@@ -535,35 +735,84 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
     if (R < 0)
         return false;
     constexpr int TW = 64 * V;
-    constexpr int KF = 4; // rows per wave per round of the fused kernel
     const int strips = (cols + TW - 1) / TW;
-    // segment length: several thousand blocks so that the chip stays full through the tail, but segments
-    // long enough that the 2R halo rows (re-read and row-filtered again) stay a small share on large planes
-    long long want = 1536;
-    long long per_row_blocks = (long long)strips * B;
-    int seg = (int)(((long long)rows * per_row_blocks + want - 1) / want);
-    if (seg < 16)
-        seg = 16;
-    if (seg > rows)
-        seg = rows;
-    seg = (seg + 4 * KF - 1) / (4 * KF) * (4 * KF);
-    dim3 g(strips, (rows + seg - 1) / seg, B);
+    const long long per_row = (long long)strips * B;
+    if (blur_use_ring()) {
+        // workgroup-shared LDS ring variant
+        constexpr int KF = 4; // rows per wave per round
+        long long want = 1536;
+        int seg = (int)(((long long)rows * per_row + want - 1) / want);
+        if (seg < 16)
+            seg = 16;
+        if (seg > rows)
+            seg = rows;
+        seg = (seg + 4 * KF - 1) / (4 * KF) * (4 * KF);
+        dim3 g(strips, (rows + seg - 1) / seg, B);
 #define SG_FUSED_CASE(RR)                                                                                             \
     case RR:                                                                                                          \
-        blur_fused_k<T, RR, V, KF><<<g, 256, fused_lds_bytes<T, RR, V, KF>(), s>>>(                                           \
+        blur_fused_k<T, RR, V, KF><<<g, 256, fused_lds_bytes<T, RR, V, KF>(), s>>>(                                   \
+            (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,      \
+            padded_taps<T>(taps, n, RR));                                                                             \
+        break;
+        switch (R) {
+            SG_FUSED_CASE(5)
+            SG_FUSED_CASE(6)
+            SG_FUSED_CASE(8)
+            SG_FUSED_CASE(10)
+            SG_FUSED_CASE(13)
+        default:
+            return false;
+        }
+#undef SG_FUSED_CASE
+        return true;
+    }
+    if (rows <= R || cols <= R)
+        return false; // the kernel reflects an index once; tiny planes go through the two-pass kernels
+    // Register-window variant: one segment per wave.  A wave runs for its whole segment, so the launch is
+    // sized from the wave slots of the chip (CUs x 4 SIMDs x resident waves per SIMD at this radius' register
+    // count): as many segments per strip as give about two waves per slot (measured best: one wave per slot
+    // leaves the chip idle while the slowest waves finish, many more re-read too many halo rows); never so
+    // short that the 2R halo rows (re-read and row-filtered again) dominate.
+    static const int n_cu = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+            cu = 256;
+        return cu;
+    }();
+    static const long long slot_scale = [] {
+        const char *e = getenv("SIFTGPU_BLUR_SLOTS");
+        return e ? atoll(e) : 200ll; // percent of the resident-wave slots to fill
+    }();
+    const int waves_per_simd = win_waves_per_simd(R);
+    const long long slots = (long long)n_cu * 4 * waves_per_simd * slot_scale / 100;
+    int nseg_want = (int)(slots / per_row);
+    if (nseg_want < 1)
+        nseg_want = 1;
+    int seg = (rows + nseg_want - 1) / nseg_want;
+    if (seg < 4 * R)
+        seg = 4 * R;
+    if (seg > rows)
+        seg = rows;
+    seg = (seg + 1) & ~1;
+    const int nseg = (rows + seg - 1) / seg;
+    dim3 g(strips, (nseg + 3) / 4, B);
+#define SG_WIN_CASE(RR)                                                                                               \
+    case RR:                                                                                                          \
+        blur_win_k<T, RR, V><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                                               \
             (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,      \
             padded_taps<T>(taps, n, RR));                                                                             \
         break;
     switch (R) {
-        SG_FUSED_CASE(5)
-        SG_FUSED_CASE(6)
-        SG_FUSED_CASE(8)
-        SG_FUSED_CASE(10)
-        SG_FUSED_CASE(13)
+        SG_WIN_CASE(5)
+        SG_WIN_CASE(6)
+        SG_WIN_CASE(8)
+        SG_WIN_CASE(10)
+        SG_WIN_CASE(13)
     default:
         return false;
     }
-#undef SG_FUSED_CASE
+#undef SG_WIN_CASE
     return true;
 }
 

@@ -5,9 +5,9 @@ Metric (BASELINE.json): 1080p images/s (keypoints + descriptors), whole job over
 rate of the blur kernels.  Workload: 1920x1080 synthetic frames (5-octave value noise, seeds 1000...),
 resident in HBM before the timed region; one step = one batch of `--batch` frames through the whole path
 (gray/upsample/blur, Gaussian pyramid, fused DoG+extrema, refinement, orientation, descriptors, scale
-ordering, 144-byte packed features).  With the defaults 8 steps x 32 frames = the 256-frame batch config.
+ordering, 144-byte packed features).  With the defaults 4 steps x 64 frames = the 256-frame batch config.
 
-  python bench.py --gpus 1 --steps 8 --warmup 2
+  python bench.py --gpus 1 --steps 4 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
@@ -44,12 +44,24 @@ def octave_pixels(w, h):
     return px
 
 
+def octave_dims(w, h):
+    """(rows, cols) of every octave, base = 2w x 2h."""
+    rows, cols = 2 * h, 2 * w
+    octaves = int(np.log(float(min(rows, cols))) / np.log(2.0) - 2)
+    out = []
+    for o in range(octaves):
+        out.append((rows, cols))
+        if rows > 1 and cols > 1:
+            rows, cols = rows // 2, cols // 2
+    return out
+
+
 def measured_traffic(kernel, tname, batch, width, height):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r*/traffic.json, written by
     profiles/summarise.py from separate FETCH_SIZE and WRITE_SIZE runs of this same command); None when no pass
     was collected for this kernel at this workload."""
     import glob
-    m = re.match(r"blur_fused_k<(\w+),R=(\d+)>", kernel)
+    m = re.match(r"(blur_\w+_k)<(\w+),R=(\d+)>", kernel)
     if not m:
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
@@ -61,7 +73,7 @@ def measured_traffic(kernel, tname, batch, width, height):
         if (cfg.get("batch"), cfg.get("width"), cfg.get("height")) != (batch, width, height):
             continue
         for name, d in t.items():
-            if name.startswith("sg::blur_fused_k<%s, %s," % (m.group(1), m.group(2))):
+            if name.startswith("sg::%s<%s, %s," % (m.group(1), m.group(2), m.group(3))):
                 return d["hbm_bytes_per_launch"]
     return None
 
@@ -69,9 +81,9 @@ def measured_traffic(kernel, tname, batch, width, height):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64")
@@ -216,19 +228,26 @@ def main():
     taps = [11, 11, 13, 17, 21, 27]
     radius_name = {0: 5, 1: 5, 2: 6, 3: 8, 4: 10, 5: 13}
     tname = "double" if esize == 8 else "float"
-    fused = not any(stage_ms.get("blur_row%d" % l, 0.0) > 0 for l in range(6))
+    blur_mode = os.environ.get("SIFTGPU_BLUR", "")
+    fused = blur_mode != "2pass"
+    fused_name = "blur_fused_k" if blur_mode == "ring" else "blur_win_k"
+    dims = octave_dims(W, H)
     # Algorithmic bytes of one blur launch: every pixel of the level read once and written once
     # (2 * sizeof(T) per pixel) -- per launch of the fused kernel, or per pass of the two-pass kernels.
+    # With the fused kernel in use, planes not larger than the radius take the two-pass kernels; their time
+    # is reported under blur_row<level> and they are left out of the fused kernel's bytes and launches.
     blur = {}
     tot_bytes = tot_ms = 0.0
     for kind in (("col",) if fused else ("row", "col")):
         for lvl in range(6):
             key = "blur_%s%d" % (kind, lvl)
             ms, ln = stage_ms.get(key, 0.0), stage_launches.get(key, 0)
-            per_frame_px = N0 if lvl == 0 else P
-            nbytes = 2.0 * esize * per_frame_px * B * K
+            octs = dims[:1] if lvl == 0 else dims
+            if fused:
+                octs = [d for d in octs if min(d) > radius_name[lvl]]
+            nbytes = 2.0 * esize * float(sum(r * c for r, c in octs)) * B * K
             if ms > 0:
-                kname = ("blur_fused_k<%s,R=%d>" % (tname, radius_name[lvl])) if fused else \
+                kname = ("%s<%s,R=%d>" % (fused_name, tname, radius_name[lvl])) if fused else \
                     ("blur_%s_k<%s,R=%d>" % (kind, tname, radius_name[lvl]))
                 blur[key] = {"kernel": kname, "taps": taps[lvl], "launches": int(ln), "avg_us": 1e3 * ms / max(ln, 1),
                              "GBps": nbytes / (ms * 1e-3) / 1e9, "bytes_per_launch_avg": nbytes / max(ln, 1)}

@@ -19,7 +19,7 @@ def short(name):
 
 out = []
 for p in ("sq_a", "sq_b"):
-    f = glob.glob(os.path.join(src, p, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, p, "*", "*counter_collection.csv")), key=os.path.getmtime)
     acc = defaultdict(lambda: defaultdict(float))
     nd = defaultdict(set)
     for r in csv.DictReader(open(f)):

@@ -23,13 +23,13 @@ def short(name):
     return name.split("(")[0].replace("void ", "").strip()
 
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(src, "stats", "*", "*kernel_stats.csv")), key=os.path.getmtime)
 shutil.copy(stats, os.path.join(dst, "kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_stats.json"), os.path.join(dst, "bench_under_rocprof.json"))
 
 
 def pmc(kind):
-    f = glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(src, kind, "*", "*counter_collection.csv")), key=os.path.getmtime)
     acc = defaultdict(lambda: [0.0, set()])
     for r in csv.DictReader(open(f)):
         k = short(r["Kernel_Name"])
@@ -47,7 +47,7 @@ for r in rows[:24]:
     k = short(r["Name"])
     fb, fn = fetch.get(k, (0.0, 0))
     wb, wn = write.get(k, (0.0, 0))
-    mult = 2.0 if "blur_fused" in k or "blur_row" in k or "blur_col" in k else 1.0
+    mult = 2.0 if "blur_" in k else 1.0
     f_l = mult * fb / fn if fn else 0.0
     w_l = wb / wn if wn else 0.0
     traffic[k] = {"fetch_bytes_per_launch": f_l, "write_bytes_per_launch": w_l, "fetch_correction": mult,

@@ -406,7 +406,7 @@ static size_t fused_lds_bytes()
 // resident waves per SIMD the register allocation of each radius aims at
 constexpr int win_waves_per_simd(int R) { return R <= 6 ? SG_WIN_WPE6 : (R <= 8 ? SG_WIN_WPE8 : (R <= 10 ? SG_WIN_WPE10 : SG_WIN_WPE13)); }
 
-template <typename T, int R, int V>
+template <typename T, int R, int V, bool MAPX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(win_waves_per_simd(R), win_waves_per_simd(R))))
 void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols,
                                                   int spitch, int dpitch, size_t simg, size_t dimg, int seg,
@@ -422,9 +422,11 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     T *raw = reinterpret_cast<T *>(smem_raw) + (size_t)wave * KR * RAWW;
-    const int x0 = blockIdx.x * TW;
-    const int ys = (blockIdx.y * 4 + wave) * seg;
-    if (ys >= rows)
+    // the four waves of a workgroup take four neighbouring strips of the same rows, so that the halo columns one
+    // wave reads are the columns its neighbour streams at about the same time
+    const int x0 = MAPX ? (blockIdx.x * 4 + wave) * TW : blockIdx.x * TW;
+    const int ys = MAPX ? blockIdx.y * seg : (blockIdx.y * 4 + wave) * seg;
+    if (x0 >= cols || ys >= rows)
         return; // the whole wave; there is no barrier in this kernel
     const int ye = min(ys + seg, rows);
     const int xb = x0 + lane * V;
@@ -452,7 +454,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                 T *pv = reinterpret_cast<T *>(&mainv[k]);
 #pragma unroll
                 for (int q = 0; q < V; q++)
-                    pv[q] = sr[xe[q]];
+                    pv[q] = *reinterpret_cast<const volatile T *>(sr + xe[q]); // kept apart from the vector load above
             }
             halo[k] = sr[hxr]; // lanes >= 2R load a valid (unused) pixel
         }
@@ -716,28 +718,39 @@ static void col_dispatch(const Plane &src, const Plane &dst, int B, const double
 #undef SG_COL_CASE
 }
 
-static bool blur_use_ring()
+bool blur_fused_supported(const Plane &src, int n)
 {
-    static const bool v = [] {
+    if (n <= 1)
+        return false;
+    const int R = bucket_radius(n / 2);
+    // the fused kernels reflect an index once: planes not larger than the radius go through the two-pass kernels
+    return R > 0 && src.rows > R && src.cols > R;
+}
+
+// SIFTGPU_BLUR=ring / win forces one fused variant for every radius; by default the register-window kernel
+// serves the radii whose window leaves room for several waves per SIMD and the LDS-ring kernel the widest one.
+static bool blur_use_ring(int R, size_t elem)
+{
+    static const int forced = [] {
         const char *e = getenv("SIFTGPU_BLUR");
-        return e && strcmp(e, "ring") == 0;
+        return !e ? 0 : (strcmp(e, "ring") == 0 ? 1 : (strcmp(e, "win") == 0 ? 2 : 0));
     }();
-    return v;
+    if (forced)
+        return forced == 1;
+    return elem == 8 && R > 10;
 }
 
 template <typename T, int V>
 static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s)
 {
     const int rows = src.rows, cols = src.cols;
-    if (n <= 1 || cols == 1 || rows == 1)
+    if (!blur_fused_supported(src, n))
         return false;
-    int R = bucket_radius(n / 2);
-    if (R < 0)
-        return false;
+    const int R = bucket_radius(n / 2);
     constexpr int TW = 64 * V;
     const int strips = (cols + TW - 1) / TW;
     const long long per_row = (long long)strips * B;
-    if (blur_use_ring()) {
+    if (blur_use_ring(R, sizeof(T))) {
         // workgroup-shared LDS ring variant
         constexpr int KF = 4; // rows per wave per round
         long long want = 1536;
@@ -766,8 +779,6 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
 #undef SG_FUSED_CASE
         return true;
     }
-    if (rows <= R || cols <= R)
-        return false; // the kernel reflects an index once; tiny planes go through the two-pass kernels
     // Register-window variant: one segment per wave.  A wave runs for its whole segment, so the launch is
     // sized from the wave slots of the chip (CUs x 4 SIMDs x resident waves per SIMD at this radius' register
     // count): as many segments per strip as give about two waves per slot (measured best: one wave per slot
@@ -796,12 +807,21 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
         seg = rows;
     seg = (seg + 1) & ~1;
     const int nseg = (rows + seg - 1) / seg;
-    dim3 g(strips, (nseg + 3) / 4, B);
+    static const bool mapx = [] {
+        const char *e = getenv("SIFTGPU_BLUR_MAPX");
+        return e ? atoi(e) != 0 : true;
+    }();
+    dim3 g((strips + 3) / 4, nseg, B), g0(strips, (nseg + 3) / 4, B);
 #define SG_WIN_CASE(RR)                                                                                               \
     case RR:                                                                                                          \
-        blur_win_k<T, RR, V><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                                               \
-            (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,      \
-            padded_taps<T>(taps, n, RR));                                                                             \
+        if (mapx)                                                                                                     \
+            blur_win_k<T, RR, V, true><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                                     \
+                (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
+                padded_taps<T>(taps, n, RR));                                                                         \
+        else                                                                                                          \
+            blur_win_k<T, RR, V, false><<<g0, 256, win_lds_bytes<T, RR, V>(), s>>>(                                   \
+                (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
+                padded_taps<T>(taps, n, RR));                                                                         \
         break;
     switch (R) {
         SG_WIN_CASE(5)

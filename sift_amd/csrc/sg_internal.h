@@ -75,6 +75,8 @@ void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *ta
 void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
 // Row and column pass in one launch (src != dst). Returns false, launching nothing, where only the two-pass
 // kernels apply (1-pixel-wide or -high planes, radius beyond the fast kernels).
+// true when launch_blur_fused handles this plane and tap count (else the two-pass kernels must be used)
+bool blur_fused_supported(const Plane &src, int n);
 bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
 
 // ---- detection --------------------------------------------------------------------------------

@@ -392,7 +392,7 @@ static void pack_phase(sg_ctx *c, void *out, size_t out_img_stride, unsigned int
 // blur src -> dst through the context's row-pass scratch plane
 static void blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, const double *taps, int n, int slot)
 {
-    if (c->fused_blur) {
+    if (c->fused_blur && blur_fused_supported(src, n)) {
         StageScope sc(c, SG_ST_BLUR_COL0 + slot);
         if (launch_blur_fused(src, dst, B, taps, n, c->prm.precision, c->stream))
             return;
@@ -401,12 +401,14 @@ static void blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, co
     tmp.p = c->d_tmp;
     tmp.pitch = src.pitch;
     tmp.img_stride = (size_t)src.rows * src.pitch;
+    // With the fused kernel in use the two-pass fallback (tiny planes) is timed under the row slot as a whole,
+    // so that the column slot holds the fused kernel's launches only.
     {
         StageScope sc(c, SG_ST_BLUR_ROW0 + slot);
         launch_blur_row(src, tmp, B, taps, n, c->prm.precision, c->stream);
     }
     {
-        StageScope sc(c, SG_ST_BLUR_COL0 + slot);
+        StageScope sc(c, (c->fused_blur ? SG_ST_BLUR_ROW0 : SG_ST_BLUR_COL0) + slot);
         launch_blur_col(tmp, dst, B, taps, n, c->prm.precision, c->stream);
     }
 }

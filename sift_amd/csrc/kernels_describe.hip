@@ -245,8 +245,9 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
 constexpr int kDescQueue = 960;  // queue entries (samples) per round
 constexpr int kDescCopies = 4;
 constexpr int kDescCopyStride = 130; // doubles; 128 bins + 2, so that the copies start 4 banks apart
-constexpr int kDescTab = 128;      // weight table entries of the wide-window variant
-constexpr int kDescTabSmall = 64;  // ... of the common variant (every radius below 64)
+constexpr int kDescTab = 256;      // weight table entries of the wide-window variant (one per window row/column)
+constexpr int kDescTabSmall = 128; // ... of the common variant (every radius below 64)
+constexpr int kDescHistPad = 40;   // doubles in front of the histograms: bin addresses are formed from (r0, c0) >= -1
 constexpr int kDescPackRadius = 127; // largest radius whose (row, column) pair fits the 16-bit queue entry
 
 __device__ __forceinline__ double wave_sum(double v)
@@ -298,8 +299,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                                               uint8_t *__restrict__ desc, size_t desc_img,
                                               double *__restrict__ prequant, size_t pq_img, unsigned int cap)
 {
-    __shared__ double hist[kDescCopies * kDescCopyStride];
-    __shared__ double etab[BIG ? kDescTab : kDescTabSmall];
+    __shared__ double hist_s[kDescHistPad + kDescCopies * kDescCopyStride];
+    __shared__ double etab[BIG ? kDescTab : kDescTabSmall]; // etab[k] = E[|k - radius|], k = row or column in the window
+    double *hist = hist_s + kDescHistPad;
     __shared__ unsigned short queue[kDescQueue];
     __shared__ double2 centres[5];
     const int lane = threadIdx.x;
@@ -340,10 +342,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
         for (int q = 0; q < (kDescCopies * kDescCopyStride + 63) / 64; q++)
             if (lane + 64 * q < kDescCopies * kDescCopyStride)
                 hist[lane + 64 * q] = 0.0;
-        etab[lane] = exp((lane * lane) * wcons);
-        if (BIG && radius >= 64)
-            etab[lane + 64] = exp(((lane + 64) * (lane + 64)) * wcons);
-        static_assert(kDescTab == 128 && kDescPackRadius < kDescTab, "the table covers every packed radius");
+        {
+            const double e0 = exp((lane * lane) * wcons);
+            if (lane <= radius && radius + lane < (BIG ? kDescTab : kDescTabSmall)) {
+                etab[radius + lane] = e0;
+                etab[radius - lane] = e0;
+            }
+            if (BIG && radius >= 64) {
+                const int k2 = lane + 64;
+                const double e1 = exp((k2 * k2) * wcons);
+                if (k2 <= radius && radius + k2 < kDescTab) {
+                    etab[radius + k2] = e1;
+                    etab[radius - k2] = e1;
+                }
+            }
+        }
+        static_assert(2 * kDescPackRadius + 1 <= kDescTab && 2 * (kDescTabSmall / 2 - 1) + 1 <= kDescTabSmall,
+                      "the table covers every packed window");
 
         const double cs = cos_ori * inv_shw, ss = sin_ori * inv_shw;
         const double Tm = 2.5 * shw + 1e-6;
@@ -415,7 +430,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
             if (lane < count)
                 fetch(lane);
             for (int e = lane; e < count; e += 64) {
-                const int i = (int)rn - radius, jj = (int)cn - radius;
+                const unsigned int ri = rn, ci = cn;
+                const int i = (int)ri - radius, jj = (int)ci - radius;
                 const double dx = (double)nr - (double)nl;
                 const double dy = (double)nd - (double)nu;
                 if (e + 64 < count)
@@ -427,23 +443,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                     // obin = ((pi - atan2(dy,dx)) - ori) * 8/(2 pi) = obin_c - atan2(dy,dx) in units of pi/4; the
                     // histogram index below wraps by itself, so the angle is not brought into [0, 2 pi) first
                     const double ax = fabs(dx), ay = fabs(dy);
-                    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+                    const double mx = __builtin_fmax(ax, ay), mn = __builtin_fmin(ax, ay);
                     double kq;
                     const double au = sg_atan_split(mn, mx, centres, kq);
                     double q = __builtin_fma(au, 4.0 / SG_PI, kq);
                     q = ay > ax ? 2.0 - q : q;
                     q = dx < 0.0 ? 4.0 - q : q;
-                    const double obin = dy < 0.0 ? obin_c + q : obin_c - q;
+                    const double obin = obin_c - __builtin_copysign(q, dy);
                     double weight;
                     if (BIG && !packed)
                         weight = exp((i * i + jj * jj) * wcons);
                     else
-                        weight = etab[abs(i)] * etab[abs(jj)];
+                        weight = etab[ri] * etab[ci];
                     const double mag = grad_mag * weight;
                     // InterpHistEntry
                     const double fr_ = floor(ybin), fc_ = floor(xbin), fo_ = floor(obin);
                     const int r0 = (int)fr_, c0 = (int)fc_, o0 = (int)fo_;
                     const double d_r = ybin - fr_, d_c = xbin - fc_, d_o = obin - fo_;
+                    // the eight bins lie at fixed distances from the (r0, c0) cell in the two orientation columns
+                    double *hb = h + (r0 * 4 + c0) * 8;
+                    double *hb0 = hb + (o0 & 7), *hb1 = hb + ((o0 + 1) & 7);
+                    const double w_o0 = 1.0 - d_o, w_o1 = d_o;
 #pragma unroll
                     for (int rr = 0; rr <= 1; rr++) {
                         int rb = r0 + rr;
@@ -454,12 +474,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                                 int cb = c0 + cc;
                                 if (cb >= 0 && cb < 4) {
                                     double v_c = v_r * ((cc == 0) ? 1.0 - d_c : d_c);
-#pragma unroll
-                                    for (int oo = 0; oo <= 1; oo++) {
-                                        int ob = (o0 + oo) & 7;
-                                        double v_o = v_c * ((oo == 0) ? 1.0 - d_o : d_o);
-                                        lds_add(&h[(rb * 4 + cb) * 8 + ob], v_o);
-                                    }
+                                    lds_add(hb0 + (rr * 4 + cc) * 8, v_c * w_o0);
+                                    lds_add(hb1 + (rr * 4 + cc) * 8, v_c * w_o1);
                                 }
                             }
                         }
@@ -513,7 +529,7 @@ void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_str
     if (blocks == 0)
         return;
     dim3 g(blocks, B);
-    const bool big = max_radius >= kDescTabSmall;
+    const bool big = 2 * max_radius + 1 > kDescTabSmall; // a window row or column beyond the small table
 #define SG_DESCR_LAUNCH(TT, BB)                                                                                       \
     descr_k<TT, BB><<<g, 64, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,         \
                                      pq_img_stride, cap)

@@ -115,6 +115,26 @@ def test_nointerval_variant(oracle):
     assert np.array_equal(got["x"], ref["x"]) and np.array_equal(got["y"], ref["y"])
 
 
+@pytest.mark.parametrize("sigma", [3.2, 8.0])
+def test_wide_windows_through_stage_entry_points(oracle, gpu64, sigma):
+    """Keypoints whose orientation / descriptor windows outgrow the common kernels' tables (orientation
+    radius >= 64 and descriptor radius > 127 at the larger sigma) go through the wide-window kernel
+    variants.  The pipeline context does not take such base scales, so the oracle's pyramid and keypoints at
+    that sigma are handed to the OrientationAssignment / DescriptorRepresentation entry points."""
+    img = oracle.vnoise5(256, 192, 5)
+    dbg = oracle.Debug(img, sigma=sigma)
+    assert len(dbg.features) > 20
+    feats = gpu64.orientation_assignment(dbg.keypoints, dbg.gauss, dbg.octaves)
+    ref = dbg.features
+    assert len(feats) == len(ref)
+    for f in FIELDS_EXACT:
+        assert np.array_equal(feats[f], ref[f]), f
+    d = np.abs(feats["ori"] - ref["ori"])
+    assert np.minimum(d, 2 * np.pi - d).max() < 1e-9
+    feats = gpu64.descriptor_representation(feats, dbg.gauss, dbg.octaves)
+    assert np.array_equal(feats["descriptor"], ref["descriptor"])
+
+
 def test_batch_device_matches_single(oracle, gpu64):
     import sift_amd
     w, h, n = 160, 120, 3

@@ -230,7 +230,13 @@ def main():
     tname = "double" if esize == 8 else "float"
     blur_mode = os.environ.get("SIFTGPU_BLUR", "")
     fused = blur_mode != "2pass"
-    fused_name = "blur_fused_k" if blur_mode == "ring" else "blur_win_k"
+
+    def fused_name(radius):
+        """The fused kernel the library launches for this radius (kernels_blur.hip: the LDS-ring variant for the
+        widest double-precision window, the register-window variant otherwise; SIFTGPU_BLUR forces one)."""
+        ring = blur_mode == "ring" or (blur_mode != "win" and esize == 8 and radius > 10)
+        return "blur_fused_k" if ring else "blur_win_k"
+
     dims = octave_dims(W, H)
     # Algorithmic bytes of one blur launch: every pixel of the level read once and written once
     # (2 * sizeof(T) per pixel) -- per launch of the fused kernel, or per pass of the two-pass kernels.
@@ -247,7 +253,7 @@ def main():
                 octs = [d for d in octs if min(d) > radius_name[lvl]]
             nbytes = 2.0 * esize * float(sum(r * c for r, c in octs)) * B * K
             if ms > 0:
-                kname = ("%s<%s,R=%d>" % (fused_name, tname, radius_name[lvl])) if fused else \
+                kname = ("%s<%s,R=%d>" % (fused_name(radius_name[lvl]), tname, radius_name[lvl])) if fused else \
                     ("blur_%s_k<%s,R=%d>" % (kind, tname, radius_name[lvl]))
                 blur[key] = {"kernel": kname, "taps": taps[lvl], "launches": int(ln), "avg_us": 1e3 * ms / max(ln, 1),
                              "GBps": nbytes / (ms * 1e-3) / 1e9, "bytes_per_launch_avg": nbytes / max(ln, 1)}

@@ -40,8 +40,8 @@ def pmc(kind):
 
 fetch, write = pmc("fetch"), pmc("write")
 rows = list(csv.DictReader(open(stats)))
-traffic = {"_config": {"batch": 32, "width": 1920, "height": 1080, "precision": "f64", "command": "python bench.py"}}
-lines = ["# rocprofv3 summary (%s): `python bench.py` (8 steps x 32 frames 1920x1080, f64, one context)" % tag, "",
+traffic = {"_config": {"batch": 64, "width": 1920, "height": 1080, "precision": "f64", "command": "python bench.py"}}
+lines = ["# rocprofv3 summary (%s): `python bench.py` (4 steps x 64 frames 1920x1080, f64, one context)" % tag, "",
          "| kernel | calls | avg us | total ms | % | FETCH_SIZE MB/launch (x2 for blur) | WRITE_SIZE MB/launch |", "|---|---|---|---|---|---|---|"]
 for r in rows[:24]:
     k = short(r["Name"])

@@ -408,9 +408,9 @@ constexpr int win_waves_per_simd(int R) { return R <= 6 ? SG_WIN_WPE6 : (R <= 8 
 
 template <typename T, int R, int V, bool MAPX>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(win_waves_per_simd(R), win_waves_per_simd(R))))
-void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols,
-                                                  int spitch, int dpitch, size_t simg, size_t dimg, int seg,
-                                                  Taps<T> taps)
+void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols, int spitch, int dpitch, size_t simg,
+                size_t dimg, int seg, Taps<T> taps, T *__restrict__ dec, int dec_rows, int dec_cols, int dec_pitch,
+                size_t dec_img)
 {
     typedef typename VecOf<T, V>::type vec_t;
     constexpr int TW = 64 * V;
@@ -548,6 +548,15 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                         for (int e = 0; e < V; e++)
                             if (xb + e < cols)
                                 dr[xb + e] = pa[e];
+                    }
+                    // DownSample (reference sift/sift.cpp:59-103) of the level just written: dec(m, n) = dst(2m, 2n).
+                    // ys and n0 are even, so the even rows are the even k.
+                    if ((k & 1) == 0 && dec != nullptr && (y >> 1) < dec_rows) {
+                        T *dd = dec + blockIdx.z * dec_img + (size_t)(y >> 1) * dec_pitch;
+#pragma unroll
+                        for (int e = 0; e < V; e += 2)
+                            if (((xb + e) >> 1) < dec_cols)
+                                dd[(xb + e) >> 1] = pa[e];
                     }
                 }
             }
@@ -741,7 +750,8 @@ static bool blur_use_ring(int R, size_t elem)
 }
 
 template <typename T, int V>
-static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s)
+static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, const Plane *dec,
+                           hipStream_t s)
 {
     const int rows = src.rows, cols = src.cols;
     if (!blur_fused_supported(src, n))
@@ -751,6 +761,8 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
     const int strips = (cols + TW - 1) / TW;
     const long long per_row = (long long)strips * B;
     if (blur_use_ring(R, sizeof(T))) {
+        if (dec)
+            return false; // only the register-window kernel writes the decimated copy (blur_fused_decimates)
         // workgroup-shared LDS ring variant
         constexpr int KF = 4; // rows per wave per round
         long long want = 1536;
@@ -807,6 +819,9 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
         seg = rows;
     seg = (seg + 1) & ~1;
     const int nseg = (rows + seg - 1) / seg;
+    T *dec_p = dec ? (T *)dec->p : nullptr;
+    const int dec_rows = dec ? dec->rows : 0, dec_cols = dec ? dec->cols : 0, dec_pitch = dec ? dec->pitch : 0;
+    const size_t dec_img = dec ? dec->img_stride : 0;
     static const bool mapx = [] {
         const char *e = getenv("SIFTGPU_BLUR_MAPX");
         return e ? atoi(e) != 0 : true;
@@ -817,11 +832,11 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
         if (mapx)                                                                                                     \
             blur_win_k<T, RR, V, true><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                                     \
                 (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
-                padded_taps<T>(taps, n, RR));                                                                         \
+                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                          \
         else                                                                                                          \
             blur_win_k<T, RR, V, false><<<g0, 256, win_lds_bytes<T, RR, V>(), s>>>(                                   \
                 (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
-                padded_taps<T>(taps, n, RR));                                                                         \
+                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                          \
         break;
     switch (R) {
         SG_WIN_CASE(5)
@@ -836,11 +851,18 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
     return true;
 }
 
-bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s)
+bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+                       const Plane *dec)
 {
     if (prec == SG_F64)
-        return fused_dispatch<double, 2>(src, dst, B, taps, n, s);
-    return fused_dispatch<float, 4>(src, dst, B, taps, n, s);
+        return fused_dispatch<double, 2>(src, dst, B, taps, n, dec, s);
+    return fused_dispatch<float, 4>(src, dst, B, taps, n, dec, s);
+}
+
+bool blur_fused_decimates(const Plane &src, int n, int prec)
+{
+    return blur_fused_supported(src, n) && src.rows > 1 && src.cols > 1 &&
+           !blur_use_ring(bucket_radius(n / 2), prec == SG_F64 ? 8 : 4);
 }
 
 void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s)

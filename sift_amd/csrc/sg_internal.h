@@ -77,7 +77,10 @@ void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *ta
 // kernels apply (1-pixel-wide or -high planes, radius beyond the fast kernels).
 // true when launch_blur_fused handles this plane and tap count (else the two-pass kernels must be used)
 bool blur_fused_supported(const Plane &src, int n);
-bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
+bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+                       const Plane *dec = nullptr);
+// true when launch_blur_fused can also write the 2:1 decimated copy of its output (DownSample) into `dec`
+bool blur_fused_decimates(const Plane &src, int n, int prec);
 
 // ---- detection --------------------------------------------------------------------------------
 void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words, size_t words_img_stride,

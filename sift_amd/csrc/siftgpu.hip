@@ -390,12 +390,15 @@ static void pack_phase(sg_ctx *c, void *out, size_t out_img_stride, unsigned int
 }
 
 // blur src -> dst through the context's row-pass scratch plane
-static void blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, const double *taps, int n, int slot)
+// dec (optional): receives the 2:1 decimated copy of dst when the fused kernel can write it; returns whether it did.
+static bool blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, const double *taps, int n, int slot,
+                        const Plane *dec = nullptr)
 {
     if (c->fused_blur && blur_fused_supported(src, n)) {
         StageScope sc(c, SG_ST_BLUR_COL0 + slot);
-        if (launch_blur_fused(src, dst, B, taps, n, c->prm.precision, c->stream))
-            return;
+        const bool with_dec = dec && blur_fused_decimates(src, n, c->prm.precision);
+        if (launch_blur_fused(src, dst, B, taps, n, c->prm.precision, c->stream, with_dec ? dec : nullptr))
+            return with_dec;
     }
     Plane tmp = src;
     tmp.p = c->d_tmp;
@@ -411,6 +414,7 @@ static void blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, co
         StageScope sc(c, (c->fused_blur ? SG_ST_BLUR_ROW0 : SG_ST_BLUR_COL0) + slot);
         launch_blur_col(tmp, dst, B, taps, n, c->prm.precision, c->stream);
     }
+    return false;
 }
 
 static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, int ch, size_t stride, size_t img_stride)
@@ -439,8 +443,9 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
         launch_gray_upsample(d_imgs, h, w, ch, stride, img_stride, up, B, prec, s);
     }
     blur_planes(c, up, c->level[0][0], B, c->taps[0], c->ntaps[0], 0);
+    bool have_base = true; // level 0 of the octave is in place
     for (int o = 0; o < c->octaves; o++) {
-        if (o > 0) {
+        if (!have_base) {
             StageScope sc(c, SG_ST_DOWNSAMPLE);
             if (c->rows[o] == c->rows[o - 1]) // a dimension <= 1: DownSample copies (sift.cpp:64-68)
                 (void)hipMemcpyAsync(c->level[o][0].p, c->level[o - 1][3].p,
@@ -448,8 +453,15 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
             else
                 launch_downsample(c->level[o - 1][3], c->level[o][0], B, prec, s);
         }
-        for (int l = 1; l < kLevels; l++)
-            blur_planes(c, c->level[o][l - 1], c->level[o][l], B, c->taps[l], c->ntaps[l], l);
+        have_base = false;
+        for (int l = 1; l < kLevels; l++) {
+            // the blur that produces level 3 also writes the next octave's level 0 (its 2:1 decimation) when it can
+            const bool want_dec = l == 3 && o + 1 < c->octaves && c->rows[o + 1] != c->rows[o];
+            const bool wrote = blur_planes(c, c->level[o][l - 1], c->level[o][l], B, c->taps[l], c->ntaps[l], l,
+                                           want_dec ? &c->level[o + 1][0] : nullptr);
+            if (want_dec && wrote)
+                have_base = true;
+        }
     }
     detect_phase(c, c->tab, c->n_words, B, c->prm.nointerval);
     orient_phase(c, c->tab, B, ori_max_radius(c->prm));

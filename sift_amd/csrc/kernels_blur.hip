@@ -406,7 +406,7 @@ static size_t fused_lds_bytes()
 // resident waves per SIMD the register allocation of each radius aims at
 constexpr int win_waves_per_simd(int R) { return R <= 6 ? SG_WIN_WPE6 : (R <= 8 ? SG_WIN_WPE8 : (R <= 10 ? SG_WIN_WPE10 : SG_WIN_WPE13)); }
 
-template <typename T, int R, int V, bool MAPX>
+template <typename T, int R, int V, bool MAPX, bool UPS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(win_waves_per_simd(R), win_waves_per_simd(R))))
 void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols, int spitch, int dpitch, size_t simg,
                 size_t dimg, int seg, Taps<T> taps, T *__restrict__ dec, int dec_rows, int dec_cols, int dec_pitch,
@@ -443,10 +443,62 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
 
     vec_t mainv[KR];
     T halo[KR];
+    // UPS: the input plane is the 2x upsampling (reference UpSample, sift/sift.cpp:111-175) of a double gray plane
+    // of rows/2 x cols/2 pixels that `src` points at (spitch, simg are that plane's); its pixels are formed here
+    // instead of being read.  Output (Y, X) with Y' = min(Y, rows-3), X' = min(X, cols-3) (the last two rows and
+    // columns repeat row rows-3 and column cols-3), i = Y'/2, j = X'/2:  s(i,j) | (s(i,j)+s(i,j+1))/2 |
+    // (s(i,j)+s(i+1,j))/2 | (s(i+1,j)+s(i,j)+s(i+1,j+1)+s(i,j+1))/4  by the parities of Y' and X'.
+    const double *gsrc = reinterpret_cast<const double *>(src) + blockIdx.z * simg;
+    int uj[V], uo[V]; // j and column parity of the lane's elements, and of its halo column
+#pragma unroll
+    for (int q = 0; q < V; q++) {
+        const int xc = min(xe[q], cols - 3);
+        uj[q] = xc >> 1;
+        uo[q] = xc & 1;
+    }
+    const int hxc = min(hxr, cols - 3);
+    const int hj = hxc >> 1, ho = hxc & 1;
+    const bool strip_inner = x0 + TW <= cols - 2; // wave-uniform: no element of the strip is a repeated column
+    auto up_value = [&](const double *g0, const double *g1, bool oddr, int j, int oc) -> T {
+        const double s00 = g0[j], s01 = g0[j + 1];
+        if (oddr) {
+            const double s10 = g1[j], s11 = g1[j + 1];
+            return (T)(oc ? (s10 + s00 + s11 + s01) / 4 : (s00 + s10) / 2);
+        }
+        return (T)(oc ? (s00 + s01) / 2 : s00);
+    };
     auto fetch = [&](int t) {
 #pragma unroll
         for (int k = 0; k < KR; k++) {
             const int yy = reflect101_once(ys - R + KR * t + k, rows);
+            if (UPS) {
+                const int yc = min(yy, rows - 3);
+                const bool oddr = (yc & 1) != 0; // wave-uniform
+                const double *g0 = gsrc + (size_t)(yc >> 1) * spitch, *g1 = g0 + spitch;
+                T *pv = reinterpret_cast<T *>(&mainv[k]);
+                if (strip_inner) {
+                    // the V elements are (even, odd) column pairs over V/2 source columns
+#pragma unroll
+                    for (int q = 0; q < V; q += 2) {
+                        const int j = (xb + q) >> 1;
+                        const double s00 = g0[j], s01 = g0[j + 1];
+                        if (oddr) {
+                            const double s10 = g1[j], s11 = g1[j + 1];
+                            pv[q] = (T)((s00 + s10) / 2);
+                            pv[q + 1] = (T)((s10 + s00 + s11 + s01) / 4);
+                        } else {
+                            pv[q] = (T)s00;
+                            pv[q + 1] = (T)((s00 + s01) / 2);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < V; q++)
+                        pv[q] = up_value(g0, g1, oddr, uj[q], uo[q]);
+                }
+                halo[k] = up_value(g0, g1, oddr, hj, ho);
+                continue;
+            }
             const T *sr = s + (size_t)yy * spitch;
             if (strip_full) {
                 mainv[k] = *reinterpret_cast<const vec_t *>(sr + xb);
@@ -849,6 +901,52 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
     }
 #undef SG_WIN_CASE
     return true;
+}
+
+// Upsampling form: `gray` is a double plane of dst.rows/2 x dst.cols/2; dst = blur(UpSample(gray)).  Instantiated
+// for the radius of the pyramid's base blur only.
+template <typename T, int V>
+static bool ups_dispatch(const Plane &gray, const Plane &dst, int B, const double *taps, int n, hipStream_t s)
+{
+    constexpr int R = 5;
+    const int rows = dst.rows, cols = dst.cols;
+    if (rows != 2 * gray.rows || cols != 2 * gray.cols || gray.rows < 2 || gray.cols < 2 || n <= 1 ||
+        bucket_radius(n / 2) != R || rows <= R || cols <= R)
+        return false;
+    constexpr int TW = 64 * V;
+    const int strips = (cols + TW - 1) / TW;
+    const long long per_row = (long long)strips * B;
+    int n_cu = 256, dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
+        n_cu = 256;
+    const long long slots = (long long)n_cu * 4 * win_waves_per_simd(R) * 2;
+    int nseg_want = (int)(slots / per_row);
+    if (nseg_want < 1)
+        nseg_want = 1;
+    int seg = (rows + nseg_want - 1) / nseg_want;
+    if (seg < 4 * R)
+        seg = 4 * R;
+    if (seg > rows)
+        seg = rows;
+    seg = (seg + 1) & ~1;
+    const int nseg = (rows + seg - 1) / seg;
+    dim3 g((strips + 3) / 4, nseg, B);
+    blur_win_k<T, R, V, true, true><<<g, 256, win_lds_bytes<T, R, V>(), s>>>(
+        (const T *)gray.p, (T *)dst.p, rows, cols, gray.pitch, dst.pitch, gray.img_stride, dst.img_stride, seg,
+        padded_taps<T>(taps, n, R), nullptr, 0, 0, 0, 0);
+    return true;
+}
+
+bool launch_blur_fused_upsampled(const Plane &gray, const Plane &dst, int B, const double *taps, int n, int prec,
+                                 hipStream_t s)
+{
+    const char *e = getenv("SIFTGPU_BLUR");
+    if (e && strcmp(e, "win") != 0)
+        return false; // another variant is forced
+    if (prec == SG_F64)
+        return ups_dispatch<double, 2>(gray, dst, B, taps, n, s);
+    return ups_dispatch<float, 4>(gray, dst, B, taps, n, s);
 }
 
 bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,

@@ -79,6 +79,10 @@ void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *ta
 bool blur_fused_supported(const Plane &src, int n);
 bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
                        const Plane *dec = nullptr);
+// dst = blur(UpSample(gray)) in one launch; gray is a double plane of half dst's size.  False when the form does not
+// apply (the caller then upsamples into a plane and blurs that).
+bool launch_blur_fused_upsampled(const Plane &gray, const Plane &dst, int B, const double *taps, int n, int prec,
+                                 hipStream_t s);
 // true when launch_blur_fused can also write the 2:1 decimated copy of its output (DownSample) into `dec`
 bool blur_fused_decimates(const Plane &src, int n, int prec);
 

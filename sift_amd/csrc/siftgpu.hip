@@ -438,11 +438,31 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
     up.cols = 2 * w;
     up.pitch = pitch_of(2 * w);
     up.img_stride = (size_t)up.rows * up.pitch;
-    {
-        StageScope sc(c, SG_ST_PREP);
-        launch_gray_upsample(d_imgs, h, w, ch, stride, img_stride, up, B, prec, s);
+    // Base image (CreateInitSmoothGray, sift.cpp:335-346).  Preferred form: the gray plane at input resolution
+    // (always double, so that a float pyramid rounds once) and one blur launch that forms the upsampled pixels
+    // itself; otherwise gray + upsample into a plane, then the blur.
+    bool base_done = false;
+    if (c->fused_blur && h >= 2 && w >= 2) {
+        Plane gray;
+        gray.p = c->d_up; // 2h x 2w elements of T hold h x w doubles
+        gray.rows = h;
+        gray.cols = w;
+        gray.pitch = pitch_of(w);
+        gray.img_stride = (size_t)gray.rows * gray.pitch;
+        {
+            StageScope sc(c, SG_ST_PREP);
+            launch_gray(d_imgs, h, w, ch, stride, img_stride, gray, B, SG_F64, s);
+        }
+        StageScope sc(c, SG_ST_BLUR_COL0);
+        base_done = launch_blur_fused_upsampled(gray, c->level[0][0], B, c->taps[0], c->ntaps[0], prec, s);
     }
-    blur_planes(c, up, c->level[0][0], B, c->taps[0], c->ntaps[0], 0);
+    if (!base_done) {
+        {
+            StageScope sc(c, SG_ST_PREP);
+            launch_gray_upsample(d_imgs, h, w, ch, stride, img_stride, up, B, prec, s);
+        }
+        blur_planes(c, up, c->level[0][0], B, c->taps[0], c->ntaps[0], 0);
+    }
     bool have_base = true; // level 0 of the octave is in place
     for (int o = 0; o < c->octaves; o++) {
         if (!have_base) {

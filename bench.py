@@ -61,8 +61,9 @@ def measured_traffic(kernel, tname, batch, width, height):
     profiles/summarise.py from separate FETCH_SIZE and WRITE_SIZE runs of this same command); None when no pass
     was collected for this kernel at this workload."""
     import glob
-    m = re.match(r"(blur_\w+_k)<(\w+),R=(\d+)>", kernel)
-    if not m:
+    m = re.match(r"(blur_\w+_k)<(\w+),R=(\d+)(,upsampling)?>", kernel)
+    d = re.match(r"detect_k<(\w+)>", kernel)
+    if not m and not d:
         return None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")), reverse=True):
         try:
@@ -72,9 +73,12 @@ def measured_traffic(kernel, tname, batch, width, height):
         cfg = t.get("_config", {})
         if (cfg.get("batch"), cfg.get("width"), cfg.get("height")) != (batch, width, height):
             continue
-        for name, d in t.items():
-            if name.startswith("sg::%s<%s, %s," % (m.group(1), m.group(2), m.group(3))):
-                return d["hbm_bytes_per_launch"]
+        for name, rec in t.items():
+            if d and name.startswith("sg::detect_k<%s," % d.group(1)):
+                return rec["hbm_bytes_per_launch"]
+            if m and name.startswith("sg::%s<%s, %s," % (m.group(1), m.group(2), m.group(3))):
+                if m.group(1) != "blur_win_k" or name.endswith("true>") == bool(m.group(4)):
+                    return rec["hbm_bytes_per_launch"]
     return None
 
 
@@ -252,8 +256,12 @@ def main():
             if fused:
                 octs = [d for d in octs if min(d) > radius_name[lvl]]
             nbytes = 2.0 * esize * float(sum(r * c for r, c in octs)) * B * K
+            ups = fused and lvl == 0 and blur_mode in ("", "win")
+            if ups:  # the base blur reads the double gray plane at input resolution instead of an upsampled plane
+                nbytes = (esize * float(dims[0][0] * dims[0][1]) + 8.0 * W * H) * B * K
             if ms > 0:
-                kname = ("%s<%s,R=%d>" % (fused_name(radius_name[lvl]), tname, radius_name[lvl])) if fused else \
+                kname = ("%s<%s,R=%d%s>" % (fused_name(radius_name[lvl]), tname, radius_name[lvl],
+                                             ",upsampling" if ups else "")) if fused else \
                     ("blur_%s_k<%s,R=%d>" % (kind, tname, radius_name[lvl]))
                 blur[key] = {"kernel": kname, "taps": taps[lvl], "launches": int(ln), "avg_us": 1e3 * ms / max(ln, 1),
                              "GBps": nbytes / (ms * 1e-3) / 1e9, "bytes_per_launch_avg": nbytes / max(ln, 1)}
@@ -266,28 +274,37 @@ def main():
         e["ms"] += d["avg_us"] * d["launches"] * 1e-3
         e["launches"] += d["launches"]
         e["bytes"] += d["bytes_per_launch_avg"] * d["launches"]
+    det_ms = stage_ms.get("detect", 0.0)
+    detect = None
+    if det_ms > 0:
+        det_bytes = 6.0 * esize * P * B * K  # the six Gaussian levels of every octave, read once
+        det_ln = int(stage_launches.get("detect", 0))
+        detect = {"kernel": "detect_k<%s> (fused DoG + 3x3x3 extrema scan; per-octave launches)" % tname,
+                  "launches": det_ln, "GBps": det_bytes / (det_ms * 1e-3) / 1e9,
+                  "frac": det_bytes / (det_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
+        by_kernel["detect_k<%s>" % tname] = {"ms": det_ms, "launches": det_ln, "bytes": det_bytes, "taps": 0}
+    # roofline: the HBM-side (pyramid) kernel with the largest share of the timed region -- a blur instantiation or the
+    # fused DoG + extrema scan.  The histogram kernels (orientation, descriptors) are VALU/LDS-atomic work and are
+    # reported as time only.
     roofline = None
     if by_kernel:
         dom = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
         e = by_kernel[dom]
         gbps = e["bytes"] / (e["ms"] * 1e-3) / 1e9
+        if dom.startswith("detect_k"):
+            what = " (six Gaussian levels -> DoG -> 3x3x3 extrema bitmap; all octaves' launches)"
+        elif fused:
+            what = " (row + column pass of a %d-tap Gaussian in one launch; all octaves' launches)" % e["taps"]
+        else:
+            what = " (%d-tap pass; all octaves' launches)" % e["taps"]
         roofline = {
-            "bound": "hbm",
-            "kernel": dom + (" (row + column pass of a %d-tap Gaussian in one launch; all octaves' launches)" % e["taps"]
-                             if fused else " (%d-tap pass; all octaves' launches)" % e["taps"]),
+            "bound": "hbm", "kernel": dom + what,
             "achieved": gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": gbps / HBM_PEAK_GBPS,
             "traffic": measured_traffic(dom, tname, B, W, H),
             "launches": e["launches"], "avg_launch_us": 1e3 * e["ms"] / e["launches"],
             "algorithmic_bytes_per_launch": e["bytes"] / e["launches"],
             "all_blur_launches_GBps": (tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else None,
         }
-    det_ms = stage_ms.get("detect", 0.0)
-    detect = None
-    if det_ms > 0:
-        det_bytes = 6.0 * esize * P * B * K  # the six Gaussian levels of every octave, read once
-        detect = {"kernel": "detect_k<%s> (fused DoG + 3x3x3 extrema scan; per-octave launches)" % tname,
-                  "launches": int(stage_launches.get("detect", 0)), "GBps": det_bytes / (det_ms * 1e-3) / 1e9,
-                  "frac": det_bytes / (det_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
 
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1:

@@ -2,8 +2,9 @@
 """Summarise gpurun_out/prof_<tag>/ (written by profiles/collect.sh) into profiles/<tag>/:
 kernel_stats.csv (rocprofv3 --stats, verbatim), summary.md, traffic.json (HBM-side bytes per launch per kernel).
 
-FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE counts a 128-byte request of a wide (16 B/lane)
-streaming read as 64 bytes, so it is doubled for the blur kernels, whose reads are of that shape."""
+FETCH_SIZE / WRITE_SIZE are in KiB.  On gfx950 FETCH_SIZE reports half of the bytes of a coalesced streaming
+read (16 B and 8 B per lane alike; calibration in profiles/r01/fetch_calibration.md), so it is doubled for the blur
+kernels and the extrema scan, whose reads are of those shapes."""
 import csv
 import glob
 import json
@@ -42,12 +43,12 @@ fetch, write = pmc("fetch"), pmc("write")
 rows = list(csv.DictReader(open(stats)))
 traffic = {"_config": {"batch": 64, "width": 1920, "height": 1080, "precision": "f64", "command": "python bench.py"}}
 lines = ["# rocprofv3 summary (%s): `python bench.py` (4 steps x 64 frames 1920x1080, f64, one context)" % tag, "",
-         "| kernel | calls | avg us | total ms | % | FETCH_SIZE MB/launch (x2 for blur) | WRITE_SIZE MB/launch |", "|---|---|---|---|---|---|---|"]
+         "| kernel | calls | avg us | total ms | % | FETCH_SIZE MB/launch (x2 for blur and detect) | WRITE_SIZE MB/launch |", "|---|---|---|---|---|---|---|"]
 for r in rows[:24]:
     k = short(r["Name"])
     fb, fn = fetch.get(k, (0.0, 0))
     wb, wn = write.get(k, (0.0, 0))
-    mult = 2.0 if "blur_" in k else 1.0
+    mult = 2.0 if ("blur_" in k or "detect_k" in k) else 1.0  # calibrated shapes: r01/fetch_calibration.md
     f_l = mult * fb / fn if fn else 0.0
     w_l = wb / wn if wn else 0.0
     traffic[k] = {"fetch_bytes_per_launch": f_l, "write_bytes_per_launch": w_l, "fetch_correction": mult,

@@ -288,7 +288,10 @@ static void detect_phase(sg_ctx *c, const OctaveTab &tab, unsigned int n_words, 
     (void)ch3;
     const double thresh = 0.5 * 0.03 / 3; // 0.5 * DXTHRESHOLD / intervals (sift.cpp:924)
     {
-        StageScope sc(c, SG_ST_DETECT, tab.octaves);
+        int scanned = 0; // octaves that have rows and columns inside the border: the ones launch_detect launches for
+        for (int o = 0; o < tab.octaves; o++)
+            scanned += tab.nrows[o] > 0 && tab.wpr[o] > 0;
+        StageScope sc(c, SG_ST_DETECT, scanned);
         for (int o = 0; o < tab.octaves; o++)
             launch_detect(tab, o, B, c->d_words, c->words_img, ch1, c->chunks_total, c->d_ctr, thresh, nointerval, prec, s);
     }

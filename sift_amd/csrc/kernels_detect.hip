@@ -26,6 +26,26 @@ __device__ __forceinline__ double vmin(double a, double b) { return __builtin_fm
 __device__ __forceinline__ float vmax(float a, float b) { return __builtin_fmaxf(a, b); }
 __device__ __forceinline__ float vmin(float a, float b) { return __builtin_fminf(a, b); }
 
+// Value of the neighbouring lane: UP = true gives lane i the value of lane i-1 (lane 0 gets `edge`), UP = false the
+// value of lane i+1 (lane 63 gets `edge`).  One DPP move per dword.
+template <bool UP>
+__device__ __forceinline__ int wave_shift_dword(int v, int edge)
+{
+    return UP ? __builtin_amdgcn_update_dpp(edge, v, 0x138, 0xf, 0xf, false)  // wave_shr:1
+              : __builtin_amdgcn_update_dpp(edge, v, 0x130, 0xf, 0xf, false); // wave_shl:1
+}
+template <bool UP>
+__device__ __forceinline__ double wave_shift(double v, double edge)
+{
+    return __hiloint2double(wave_shift_dword<UP>(__double2hiint(v), __double2hiint(edge)),
+                            wave_shift_dword<UP>(__double2loint(v), __double2loint(edge)));
+}
+template <bool UP>
+__device__ __forceinline__ float wave_shift(float v, float edge)
+{
+    return __int_as_float(wave_shift_dword<UP>(__float_as_int(v), __float_as_int(edge)));
+}
+
 // ---- fused DoG + extrema scan ----------------------------------------------------------------------
 // One wave owns a 64-pixel segment of RS consecutive rows and all three scanned layers.  Each lane
 // keeps, for the 5 DoG levels, the extremes of a 3-row x 3-column window as running column/row partial
@@ -40,12 +60,14 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
     const int b = blockIdx.z;
-    const int k = blockIdx.x;
+    // the four waves of a workgroup scan four neighbouring 64-pixel segments of the same rows, so that the lines a
+    // wave shares with its neighbour segment are streamed at about the same time
+    const int k = blockIdx.x * 4 + wave;
     const int x = kBorder + 64 * k + lane;
     const bool x_ok = x < cols - kBorder;
-    const int xc = x_ok ? x : cols - kBorder - 1; // clamped column for loads; results masked by x_ok
-    const int y_begin = kBorder + (blockIdx.y * 4 + wave) * RS;
-    const int y_end = min(y_begin + RS, rows - kBorder);
+    const int xc = min(x, cols - 1); // column for loads (the border columns are real pixels); results masked by x_ok
+    const int y_begin = kBorder + blockIdx.y * RS;
+    const int y_end = k < tab.wpr[o] ? min(y_begin + RS, rows - kBorder) : y_begin; // no rows for a segment past the row end
     __shared__ unsigned int blk_ctr[3];
     if (threadIdx.x < 3)
         blk_ctr[threadIdx.x] = 0;
@@ -61,37 +83,44 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
     // scanned layers in the current and next row.
     T rmx01[kDogLevels], rmn01[kDogLevels], rmx1[kDogLevels], rmn1[kDogLevels], rmx2[kDogLevels], rmn2[kDogLevels];
     T cen1[3], cen2[3];
+    // A lane loads its own column only; the DoG values of columns x-1 and x+1 come from the neighbouring lanes by
+    // wave shifts, and lanes 0 and 63 load the one column beyond the segment that no lane holds.
+    const int xe = lane == 0 ? xc - 1 : min(xc + 1, cols - 1); // used by lanes 0 and 63
+    const bool edge_lane = lane == 0 || lane == 63;
     auto load_row = [&](int y) { // fills rmx2 / rmn2 / cen2 from row y
-        size_t off = img + (size_t)y * pitch + xc;
-        T d[kDogLevels][3];
+        const size_t row = img + (size_t)y * pitch;
+        T dc[kDogLevels], de[kDogLevels]; // DoG of the lane's column; of the edge column (lanes 0, 63)
         if (FROM_DOG) {
 #pragma unroll
             for (int l = 0; l < kDogLevels; l++) {
-                const T *p = (const T *)tab.lv[o][l] + off;
-                d[l][0] = p[-1]; d[l][1] = p[0]; d[l][2] = p[1];
+                const T *p = (const T *)tab.lv[o][l] + row;
+                dc[l] = p[xc];
+                de[l] = edge_lane ? p[xe] : (T)0;
             }
         } else {
-            T g[kLevels][3];
+            T gc[kLevels], ge[kLevels];
 #pragma unroll
             for (int l = 0; l < kLevels; l++) {
-                const T *p = (const T *)tab.lv[o][l] + off;
-                g[l][0] = p[-1]; g[l][1] = p[0]; g[l][2] = p[1];
+                const T *p = (const T *)tab.lv[o][l] + row;
+                gc[l] = p[xc];
+                ge[l] = edge_lane ? p[xe] : (T)0;
             }
 #pragma unroll
             for (int l = 0; l < kDogLevels; l++) {
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-                    d[l][c] = g[l + 1][c] - g[l][c];
+                dc[l] = gc[l + 1] - gc[l];
+                de[l] = ge[l + 1] - ge[l];
             }
         }
 #pragma unroll
         for (int l = 0; l < kDogLevels; l++) {
-            rmx2[l] = vmax(vmax(d[l][0], d[l][1]), d[l][2]);
-            rmn2[l] = vmin(vmin(d[l][0], d[l][1]), d[l][2]);
+            const T left = wave_shift<true>(dc[l], de[l]);   // column x-1: lane-1's value, lane 0 keeps its edge value
+            const T right = wave_shift<false>(dc[l], de[l]); // column x+1: lane+1's value, lane 63 keeps its edge value
+            rmx2[l] = vmax(vmax(left, dc[l]), right);
+            rmn2[l] = vmin(vmin(left, dc[l]), right);
         }
 #pragma unroll
         for (int l = 0; l < 3; l++)
-            cen2[l] = d[l + 1][1];
+            cen2[l] = dc[l + 1];
     };
 
     unsigned int n00 = 0, n0 = 0, n1 = 0;
@@ -175,7 +204,7 @@ void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words
     if (tab.nrows[o] <= 0 || tab.wpr[o] <= 0)
         return;
     constexpr int RS = 16;
-    dim3 g(tab.wpr[o], (tab.nrows[o] + 4 * RS - 1) / (4 * RS), B);
+    dim3 g((tab.wpr[o] + 3) / 4, (tab.nrows[o] + RS - 1) / RS, B);
 #define SG_DET(T, FD, NI)                                                                                      \
     detect_k<T, FD, NI, RS><<<g, 256, 0, s>>>(tab, o, words, words_img_stride, chunk_sums, chunks_img_stride, \
                                               counters, thresh)

@@ -209,3 +209,23 @@ def test_stage_entry_points_chain(oracle, gpu64):
     assert np.array_equal(feats["descriptor"], dbg.features["descriptor"])
     srt = gpu64.sort_features(feats)
     assert np.array_equal(srt["descriptor"], dbg.sorted_features["descriptor"])
+
+
+@pytest.mark.parametrize("w,h,seed", [(131, 77, 3), (257, 129, 4), (64, 64, 5), (33, 47, 6), (500, 36, 8), (23, 310, 9),
+                                      (16, 16, 10), (640, 479, 11)])
+def test_ragged_sizes_match_oracle(oracle, gpu64, w, h, seed):
+    """Odd widths and heights (strips that cross the right border, rows that are not a multiple of the kernels'
+    row groups, octaves that shrink to a few pixels, planes smaller than a blur radius)."""
+    img = oracle.vnoise5(w, h, seed)
+    dbg = oracle.Debug(img)
+    got = gpu64.extract(img)
+    assert gpu64.last_octaves() == dbg.octaves
+    for o in range(dbg.octaves):
+        for l in range(6):
+            assert np.array_equal(gpu64.read_level(o, l), dbg.gauss[o * 6 + l]), "octave %d level %d" % (o, l)
+    assert gpu64.read_counters() == dbg.counters
+    ref = dbg.sorted_features
+    assert len(got) == len(ref)
+    for f in FIELDS_EXACT:
+        assert np.array_equal(got[f], ref[f]), f
+    assert np.array_equal(got["descriptor"], ref["descriptor"])

@@ -391,6 +391,9 @@ static size_t fused_lds_bytes()
 // flight during the arithmetic.  No workgroup barrier, no LDS traffic for the column pass.  Arithmetic and
 // operation order per pixel are those of the two-pass kernels above, so results are bit-identical to them;
 // HBM traffic is one read and one write per pixel (plus 2R re-read rows per segment).
+#ifndef SG_WIN_PF
+#define SG_WIN_PF 2 // iterations (row pairs) of input prefetch in the register-window kernel
+#endif
 #ifndef SG_WIN_WPE13
 #define SG_WIN_WPE13 2
 #endif
@@ -441,8 +444,11 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
     for (int q = 0; q < V; q++)
         xe[q] = reflect101_once(xb + q, cols);
 
-    vec_t mainv[KR];
-    T halo[KR];
+    // Input rows are fetched PF iterations ahead of their use: the arithmetic of one iteration is shorter than the
+    // memory latency under load, and a wave has few neighbours on its SIMD to hide it.
+    constexpr int PF = UPS ? 1 : SG_WIN_PF;
+    vec_t mainv_s[PF][KR];
+    T halo_s[PF][KR];
     // UPS: the input plane is the 2x upsampling (reference UpSample, sift/sift.cpp:111-175) of a double gray plane
     // of rows/2 x cols/2 pixels that `src` points at (spitch, simg are that plane's); its pixels are formed here
     // instead of being read.  Output (Y, X) with Y' = min(Y, rows-3), X' = min(X, cols-3) (the last two rows and
@@ -467,7 +473,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
         }
         return (T)(oc ? (s00 + s01) / 2 : s00);
     };
-    auto fetch = [&](int t) {
+    auto fetch = [&](int t, vec_t *mainv, T *halo) {
 #pragma unroll
         for (int k = 0; k < KR; k++) {
             const int yy = reflect101_once(ys - R + KR * t + k, rows);
@@ -520,8 +526,13 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
         for (int e = 0; e < V; e++)
             pw[e] = (T)0;
     }
-    fetch(0);
+#pragma unroll
+    for (int p = 0; p < PF; p++)
+        if (p < n_iter)
+            fetch(p, mainv_s[p], halo_s[p]);
     for (int t = 0; t < n_iter; t++) {
+        vec_t *mainv = mainv_s[0];
+        T *halo = halo_s[0];
 #pragma unroll
         for (int j = 0; j + KR < WIN; j++)
             win[j] = win[j + KR];
@@ -538,8 +549,17 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                 raw[k * RAWW + (lane < R ? lane : TW + lane)] = halo[k];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // same-wave LDS hand-off between lanes
-        if (t + 1 < n_iter)
-            fetch(t + 1);
+        // stage 0 is consumed: the later stages move up and the row pair PF iterations ahead is requested
+#pragma unroll
+        for (int p = 0; p + 1 < PF; p++) {
+#pragma unroll
+            for (int k = 0; k < KR; k++) {
+                mainv_s[p][k] = mainv_s[p + 1][k];
+                halo_s[p][k] = halo_s[p + 1][k];
+            }
+        }
+        if (t + PF < n_iter)
+            fetch(t + PF, mainv_s[PF - 1], halo_s[PF - 1]);
 #pragma unroll
         for (int k = 0; k < KR; k++) {
             vec_t o;

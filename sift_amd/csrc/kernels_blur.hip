@@ -409,7 +409,7 @@ static size_t fused_lds_bytes()
 // resident waves per SIMD the register allocation of each radius aims at
 constexpr int win_waves_per_simd(int R) { return R <= 6 ? SG_WIN_WPE6 : (R <= 8 ? SG_WIN_WPE8 : (R <= 10 ? SG_WIN_WPE10 : SG_WIN_WPE13)); }
 
-template <typename T, int R, int V, bool MAPX, bool UPS = false>
+template <typename T, int R, int V, bool UPS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(win_waves_per_simd(R), win_waves_per_simd(R))))
 void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols, int spitch, int dpitch, size_t simg,
                 size_t dimg, int seg, Taps<T> taps, T *__restrict__ dec, int dec_rows, int dec_cols, int dec_pitch,
@@ -427,9 +427,9 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
     T *raw = reinterpret_cast<T *>(smem_raw) + (size_t)wave * KR * RAWW;
     // the four waves of a workgroup take four neighbouring strips of the same rows, so that the halo columns one
     // wave reads are the columns its neighbour streams at about the same time
-    const int x0 = MAPX ? (blockIdx.x * 4 + wave) * TW : blockIdx.x * TW;
-    const int ys = MAPX ? blockIdx.y * seg : (blockIdx.y * 4 + wave) * seg;
-    if (x0 >= cols || ys >= rows)
+    const int x0 = (blockIdx.x * 4 + wave) * TW;
+    const int ys = blockIdx.y * seg;
+    if (x0 >= cols)
         return; // the whole wave; there is no barrier in this kernel
     const int ye = min(ys + seg, rows);
     const int xb = x0 + lane * V;
@@ -808,6 +808,32 @@ bool blur_fused_supported(const Plane &src, int n)
     return R > 0 && src.rows > R && src.cols > R;
 }
 
+// Rows per wave segment of the register-window kernel.  A wave runs for its whole segment, so the launch is sized
+// from the wave slots of the chip (CUs x 4 SIMDs x resident waves per SIMD at this radius' register count): as many
+// segments per strip as give about two waves per slot (measured best: one wave per slot leaves the chip idle while
+// the slowest waves finish, many more re-read too many halo rows); never so short that the 2R halo rows (re-read
+// and row-filtered again) dominate.  per_row = strips x frames.
+static int win_segment_rows(int rows, long long per_row, int R)
+{
+    static const int n_cu = [] {
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
+            cu = 256;
+        return cu;
+    }();
+    const long long slots = (long long)n_cu * 4 * win_waves_per_simd(R) * 2;
+    int nseg_want = (int)(slots / per_row);
+    if (nseg_want < 1)
+        nseg_want = 1;
+    int seg = (rows + nseg_want - 1) / nseg_want;
+    if (seg < 4 * R)
+        seg = 4 * R;
+    if (seg > rows)
+        seg = rows;
+    return (seg + 1) & ~1; // even, so that row parity inside a segment is the image's
+}
+
 // SIFTGPU_BLUR=ring / win forces one fused variant for every radius; by default the register-window kernel
 // serves the radii whose window leaves room for several waves per SIMD and the LDS-ring kernel the widest one.
 static bool blur_use_ring(int R, size_t elem)
@@ -863,52 +889,17 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
 #undef SG_FUSED_CASE
         return true;
     }
-    // Register-window variant: one segment per wave.  A wave runs for its whole segment, so the launch is
-    // sized from the wave slots of the chip (CUs x 4 SIMDs x resident waves per SIMD at this radius' register
-    // count): as many segments per strip as give about two waves per slot (measured best: one wave per slot
-    // leaves the chip idle while the slowest waves finish, many more re-read too many halo rows); never so
-    // short that the 2R halo rows (re-read and row-filtered again) dominate.
-    static const int n_cu = [] {
-        int dev = 0, cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
-            cu = 256;
-        return cu;
-    }();
-    static const long long slot_scale = [] {
-        const char *e = getenv("SIFTGPU_BLUR_SLOTS");
-        return e ? atoll(e) : 200ll; // percent of the resident-wave slots to fill
-    }();
-    const int waves_per_simd = win_waves_per_simd(R);
-    const long long slots = (long long)n_cu * 4 * waves_per_simd * slot_scale / 100;
-    int nseg_want = (int)(slots / per_row);
-    if (nseg_want < 1)
-        nseg_want = 1;
-    int seg = (rows + nseg_want - 1) / nseg_want;
-    if (seg < 4 * R)
-        seg = 4 * R;
-    if (seg > rows)
-        seg = rows;
-    seg = (seg + 1) & ~1;
+    const int seg = win_segment_rows(rows, per_row, R);
     const int nseg = (rows + seg - 1) / seg;
     T *dec_p = dec ? (T *)dec->p : nullptr;
     const int dec_rows = dec ? dec->rows : 0, dec_cols = dec ? dec->cols : 0, dec_pitch = dec ? dec->pitch : 0;
     const size_t dec_img = dec ? dec->img_stride : 0;
-    static const bool mapx = [] {
-        const char *e = getenv("SIFTGPU_BLUR_MAPX");
-        return e ? atoi(e) != 0 : true;
-    }();
-    dim3 g((strips + 3) / 4, nseg, B), g0(strips, (nseg + 3) / 4, B);
+    dim3 g((strips + 3) / 4, nseg, B);
 #define SG_WIN_CASE(RR)                                                                                               \
     case RR:                                                                                                          \
-        if (mapx)                                                                                                     \
-            blur_win_k<T, RR, V, true><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                                     \
-                (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
-                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                          \
-        else                                                                                                          \
-            blur_win_k<T, RR, V, false><<<g0, 256, win_lds_bytes<T, RR, V>(), s>>>(                                   \
-                (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
-                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                          \
+        blur_win_k<T, RR, V><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                                               \
+            (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,      \
+            padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                              \
         break;
     switch (R) {
         SG_WIN_CASE(5)
@@ -936,23 +927,10 @@ static bool ups_dispatch(const Plane &gray, const Plane &dst, int B, const doubl
     constexpr int TW = 64 * V;
     const int strips = (cols + TW - 1) / TW;
     const long long per_row = (long long)strips * B;
-    int n_cu = 256, dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0)
-        n_cu = 256;
-    const long long slots = (long long)n_cu * 4 * win_waves_per_simd(R) * 2;
-    int nseg_want = (int)(slots / per_row);
-    if (nseg_want < 1)
-        nseg_want = 1;
-    int seg = (rows + nseg_want - 1) / nseg_want;
-    if (seg < 4 * R)
-        seg = 4 * R;
-    if (seg > rows)
-        seg = rows;
-    seg = (seg + 1) & ~1;
+    const int seg = win_segment_rows(rows, per_row, R);
     const int nseg = (rows + seg - 1) / seg;
     dim3 g((strips + 3) / 4, nseg, B);
-    blur_win_k<T, R, V, true, true><<<g, 256, win_lds_bytes<T, R, V>(), s>>>(
+    blur_win_k<T, R, V, true><<<g, 256, win_lds_bytes<T, R, V>(), s>>>(
         (const T *)gray.p, (T *)dst.p, rows, cols, gray.pitch, dst.pitch, gray.img_stride, dst.img_stride, seg,
         padded_taps<T>(taps, n, R), nullptr, 0, 0, 0, 0);
     return true;

@@ -236,10 +236,9 @@ def main():
     fused = blur_mode != "2pass"
 
     def fused_name(radius):
-        """The fused kernel the library launches for this radius (kernels_blur.hip: the LDS-ring variant for the
-        widest double-precision window, the register-window variant otherwise; SIFTGPU_BLUR forces one)."""
-        ring = blur_mode == "ring" or (blur_mode != "win" and esize == 8 and radius > 10)
-        return "blur_fused_k" if ring else "blur_win_k"
+        """The fused kernel the library launches (kernels_blur.hip: the register-window variant; the LDS-ring
+        variant with SIFTGPU_BLUR=ring)."""
+        return "blur_fused_k" if blur_mode == "ring" else "blur_win_k"
 
     dims = octave_dims(W, H)
     # Algorithmic bytes of one blur launch: every pixel of the level read once and written once

@@ -834,17 +834,17 @@ static int win_segment_rows(int rows, long long per_row, int R)
     return (seg + 1) & ~1; // even, so that row parity inside a segment is the image's
 }
 
-// SIFTGPU_BLUR=ring / win forces one fused variant for every radius; by default the register-window kernel
-// serves the radii whose window leaves room for several waves per SIMD and the LDS-ring kernel the widest one.
+// SIFTGPU_BLUR=ring selects the workgroup-shared LDS-ring variant of the fused kernel (kept for comparison); the
+// register-window variant is the default for every radius.
 static bool blur_use_ring(int R, size_t elem)
 {
-    static const int forced = [] {
+    static const bool ring = [] {
         const char *e = getenv("SIFTGPU_BLUR");
-        return !e ? 0 : (strcmp(e, "ring") == 0 ? 1 : (strcmp(e, "win") == 0 ? 2 : 0));
+        return e && strcmp(e, "ring") == 0;
     }();
-    if (forced)
-        return forced == 1;
-    return elem == 8 && R > 10;
+    (void)R;
+    (void)elem;
+    return ring;
 }
 
 template <typename T, int V>
@@ -940,7 +940,7 @@ bool launch_blur_fused_upsampled(const Plane &gray, const Plane &dst, int B, con
                                  hipStream_t s)
 {
     const char *e = getenv("SIFTGPU_BLUR");
-    if (e && strcmp(e, "win") != 0)
+    if (e && *e && strcmp(e, "win") != 0)
         return false; // another variant is forced
     if (prec == SG_F64)
         return ups_dispatch<double, 2>(gray, dst, B, taps, n, s);

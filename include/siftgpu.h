@@ -193,6 +193,28 @@ int sg_set_profiling(sg_ctx *ctx, int on);
 int sg_get_stage_times(sg_ctx *ctx, double *ms /* SG_ST_COUNT */, unsigned long long *launches /* SG_ST_COUNT */);
 int sg_reset_stage_times(sg_ctx *ctx);
 
+/* ---- descriptor matching: the step after the path in the reference's demo --------------------- */
+
+/* MatchPoint (sift/sift.h:105-110): indices into the two feature lists. */
+typedef struct sg_match_point {
+    int index_1, index_2;
+} sg_match_point;
+
+/* Brute-force matching with ratio test, the loop of the demo's main (sift/源.cpp:88-156): for every feature of
+ * f1 the Euclidean distance over the 128 descriptor values to every feature of f2, the smallest (first index on
+ * ties) and the second smallest; a match iff smallest / second < ratio (0.5 in the demo).  Distances are formed
+ * per pair (the demo's `odest`, 源.cpp:97-110, is not reset between candidates; that carry-over is not
+ * reproduced).  Descriptor values must be integers 0..255, as the path produces them (SG_E_INVALID otherwise).
+ * Matches come out in index_1 order; SG_E_CAPACITY with *n = needed count when cap is too small. */
+int sg_match(sg_ctx *ctx, const sg_keypoint *f1, size_t n1, const sg_keypoint *f2, size_t n2, double ratio,
+             sg_match_point *out, size_t cap, size_t *n);
+
+/* Device form on packed features (the output of sg_extract_batch_device): d_index2[i] = index of the match of
+ * feature i of d_f1 in d_f2, or -1; d_dist2 (optional, 2 per feature) = smallest and second smallest squared
+ * distance (0xffffffff where there is none).  Asynchronous on the context's stream; sg_sync waits. */
+int sg_match_packed_device(sg_ctx *ctx, const sg_packed_feature *d_f1, uint32_t n1, const sg_packed_feature *d_f2,
+                           uint32_t n2, double ratio, int32_t *d_index2, uint32_t *d_dist2);
+
 /* ---- device memory and synthetic input (so that callers need no HIP binding of their own) ---- */
 
 int sg_malloc(sg_ctx *ctx, size_t bytes, void **d_ptr);

@@ -99,6 +99,9 @@ def lib():
     L.so_free_pyramid.argtypes = [C.POINTER(Pyramid)]
     L.so_sift_batch.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_size_t)]
     L.so_sift_batch.restype = C.c_double
+    L.so_match.argtypes = [C.POINTER(Keypoint), C.c_size_t, C.POINTER(Keypoint), C.c_size_t, C.c_double, C.c_int,
+                           C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    L.so_match.restype = C.c_size_t
     L.so_write_features.argtypes = [C.POINTER(Keypoint), C.c_size_t, C.c_char_p]
     L.so_write_features.restype = C.c_int
     L.so_vnoise5.argtypes = [u8p, C.c_int, C.c_int, C.c_uint64]
@@ -270,3 +273,18 @@ def write_features(feats, path):
     feats = np.ascontiguousarray(feats)
     assert feats.dtype == KEYPOINT_DTYPE
     return lib().so_write_features(feats.ctypes.data_as(C.POINTER(Keypoint)), len(feats), path.encode())
+
+
+def match(f1, f2, ratio=0.5, accumulate_bug=False):
+    """Brute-force matching with ratio test (demo main, 源.cpp:88-156). Returns (pairs[n,2] int32, best2[n1,2]
+    squared distances smallest / second smallest)."""
+    f1 = np.ascontiguousarray(f1)
+    f2 = np.ascontiguousarray(f2)
+    assert f1.dtype == KEYPOINT_DTYPE and f2.dtype == KEYPOINT_DTYPE
+    i1 = np.zeros(max(len(f1), 1), dtype=np.int32)
+    i2 = np.zeros(max(len(f1), 1), dtype=np.int32)
+    best2 = np.zeros((max(len(f1), 1), 2), dtype=np.float64)
+    n = lib().so_match(f1.ctypes.data_as(C.POINTER(Keypoint)), len(f1), f2.ctypes.data_as(C.POINTER(Keypoint)), len(f2),
+                       ratio, int(accumulate_bug), i1.ctypes.data_as(C.POINTER(C.c_int)),
+                       i2.ctypes.data_as(C.POINTER(C.c_int)), best2.ctypes.data_as(C.POINTER(C.c_double)))
+    return np.stack([i1[:n], i2[:n]], axis=1), best2[:len(f1)]

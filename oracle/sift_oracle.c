@@ -16,6 +16,7 @@
 #define _GNU_SOURCE
 #include "sift_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdio.h>
@@ -944,6 +945,53 @@ int so_write_features(const so_keypoint *f, size_t n, const char *path)
 }
 
 /* ------------------------------------------------------------------ synthetic input */
+
+/* ---- descriptor matching (demo main, sift/源.cpp:88-156) ---- */
+size_t so_match(const so_keypoint *f1, size_t n1, const so_keypoint *f2, size_t n2, double ratio, int accumulate_bug,
+                int *index_1, int *index_2, double *best2)
+{
+    size_t nm = 0;
+    for (size_t i = 0; i < n1; i++) {
+        double odest = 0; /* 源.cpp:97 */
+        int min_index = 0;
+        double min_value = DBL_MAX, pen_value = DBL_MAX; /* 源.cpp:99-102 */
+        double min_sq = DBL_MAX, pen_sq = DBL_MAX;
+        for (size_t j = 0; j < n2; j++) {
+            if (!accumulate_bug)
+                odest = 0;
+            double sq = 0;
+            for (int k = 0; k < 128; k++) { /* 源.cpp:106-107 */
+                double d = f1[i].descriptor[k] - f2[j].descriptor[k];
+                odest += d * d;
+                sq += d * d;
+            }
+            odest = sqrt(odest); /* 源.cpp:110 */
+            if (odest < min_value) { /* 源.cpp:114-129 */
+                pen_value = min_value;
+                min_value = odest;
+                min_index = (int)j;
+            } else if (odest < pen_value) {
+                pen_value = odest;
+            }
+            if (sq < min_sq) {
+                pen_sq = min_sq;
+                min_sq = sq;
+            } else if (sq < pen_sq) {
+                pen_sq = sq;
+            }
+        }
+        if (best2) {
+            best2[2 * i] = min_sq;
+            best2[2 * i + 1] = pen_sq;
+        }
+        if (min_value / pen_value < ratio) { /* 源.cpp:149-155 */
+            index_1[nm] = (int)i;
+            index_2[nm] = min_index;
+            nm++;
+        }
+    }
+    return nm;
+}
 
 static uint64_t sm64(uint64_t x)
 {

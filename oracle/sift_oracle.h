@@ -125,6 +125,17 @@ double so_sift_batch(const uint8_t *imgs, int n_images, int rows, int cols, int 
 /* ---- text feature format (sift.cpp:1886-1931) ---- */
 int so_write_features(const so_keypoint *f, size_t n, const char *path);
 
+/* ---- brute-force descriptor matching with ratio test (demo main, sift/源.cpp:88-156) ----
+ * For every feature of f1: Euclidean distance to every feature of f2 over the 128 descriptor values, smallest
+ * (first index on ties: strict <) and second smallest value, match iff smallest / second < ratio (0.5 in the demo).
+ * The demo's distance variable is not reset between candidates (源.cpp:97,107,110: `odest` carries the previous
+ * square root into the next sum); accumulate_bug = 0 resets it per pair (the intended metric, what the GPU path
+ * computes), accumulate_bug = 1 reproduces the demo literally.  Returns the number of matches written to
+ * index_1 / index_2 (each with room for n1 entries), in index_1 order.  best2 (optional, n1 x 2) receives the
+ * smallest and second smallest squared distances of the reset form. */
+size_t so_match(const so_keypoint *f1, size_t n1, const so_keypoint *f2, size_t n2, double ratio, int accumulate_bug,
+                int *index_1, int *index_2, double *best2);
+
 /* ---- synthetic input: 5-octave value noise, stateless hash; b=g=r ---- */
 void so_vnoise5(uint8_t *dst /* rows x cols x 3 */, int rows, int cols, uint64_t seed);
 

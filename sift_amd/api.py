@@ -38,7 +38,7 @@ EXPORTS = (
     "sg_orientation_assignment", "sg_descriptor_representation", "sg_sort_features", "sg_last_octaves",
     "sg_level_dims", "sg_read_level", "sg_read_counters", "sg_read_keypoints", "sg_read_features_unsorted",
     "sg_set_profiling", "sg_get_stage_times", "sg_reset_stage_times", "sg_malloc", "sg_free", "sg_memcpy_h2d",
-    "sg_memcpy_d2h", "sg_synth_vnoise5",
+    "sg_memcpy_d2h", "sg_synth_vnoise5", "sg_match", "sg_match_packed_device",
 )
 
 
@@ -106,6 +106,8 @@ def load_library():
     L.sg_orientation_assignment.argtypes = [vp, vp, C.c_size_t, dpp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, szp]
     L.sg_descriptor_representation.argtypes = [vp, vp, C.c_size_t, dpp, C.c_int, C.c_int, C.c_int]
     L.sg_sort_features.argtypes = [vp, vp, C.c_size_t]
+    L.sg_match.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_double, vp, C.c_size_t, szp]
+    L.sg_match_packed_device.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_double, vp, vp]
     L.sg_last_octaves.argtypes = [vp]
     L.sg_level_dims.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.sg_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
@@ -344,6 +346,22 @@ class SiftGPU:
         feats = np.ascontiguousarray(feats).copy()
         self._check(self.lib.sg_sort_features(self.ctx, feats.ctypes.data, len(feats)))
         return feats
+
+    # ---- descriptor matching (the reference demo's loop, sift/源.cpp:88-156) ------------------------------
+    def match(self, f1, f2, ratio=0.5):
+        """Brute-force matching with ratio test on Keypoint records; returns int32 pairs [n, 2] = (index_1, index_2)."""
+        f1 = np.ascontiguousarray(f1)
+        f2 = np.ascontiguousarray(f2)
+        assert f1.dtype == KEYPOINT_DTYPE and f2.dtype == KEYPOINT_DTYPE
+        out = np.zeros((max(len(f1), 1), 2), dtype=np.int32)
+        n = C.c_size_t(0)
+        self._check(self.lib.sg_match(self.ctx, f1.ctypes.data, len(f1), f2.ctypes.data, len(f2), ratio,
+                                      out.ctypes.data, len(f1), C.byref(n)))
+        return out[: n.value]
+
+    def match_packed_device(self, d_f1, n1, d_f2, n2, d_index2, d_dist2=None, ratio=0.5):
+        """Device-pointer form on packed features (ints); asynchronous. d_index2: n1 int32; d_dist2: 2*n1 uint32 or None."""
+        self._check(self.lib.sg_match_packed_device(self.ctx, d_f1, n1, d_f2, n2, ratio, d_index2, d_dist2))
 
     # ---- inspection ------------------------------------------------------------------------------------
     def last_octaves(self):

@@ -1,0 +1,170 @@
+// kernels_match.hip -- brute-force descriptor matching with ratio test for gfx950.
+//
+// The step after the extraction path in the reference's demo (sift/源.cpp:88-156): for every feature of
+// image 1 the Euclidean distances to all features of image 2 over the 128 descriptor values, the smallest
+// (first index on ties) and the second smallest, and a match when smallest / second < ratio.
+//
+// Descriptor values are integers 0..255 (HistToDescriptor, sift/sift.cpp:1567-1597), so the squared
+// distance is an exact integer:  |a-b|^2 = |a'|^2 + |b'|^2 - 2 a'.b'  with a' = a - 128, b' = b - 128 as
+// signed bytes (the shift cancels in the difference).  The dot products are one dense N x M x 128
+// contraction and run on the matrix cores (v_mfma_i32_32x32x32_i8, exact in int32); the running
+// smallest / second smallest per feature is kept by the lanes that own the output column.
+#include "sg_internal.h"
+
+namespace sg {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kMatchPadNorm = 0x3fffffff; // squared norm given to the padding rows: never the smallest
+
+// ---- preparation: descriptors -> signed-byte rows and squared norms ------------------------------------
+// 32 lanes per feature, four values per lane.  MODE 0: sg_packed_feature (128 u8 at byte 16, 144-byte
+// records); MODE 1: sg_keypoint (128 doubles at byte 88, 1120-byte records).  Rows n .. n_pad-1 are zero
+// with the padding norm.  A value that is not an integer in 0..255 sets *bad.
+template <int MODE>
+__global__ __launch_bounds__(256) void match_prep_k(const unsigned char *feats, unsigned int n, unsigned int n_pad,
+                                                    signed char *rows, int *norms, unsigned int *bad)
+{
+    const unsigned int f = blockIdx.x * 8u + (threadIdx.x >> 5);
+    const int part = threadIdx.x & 31;
+    if (f >= n_pad)
+        return;
+    int v[4] = {128, 128, 128, 128}; // shifted value 0 for the padding rows
+    bool ok = true;
+    if (f < n) {
+        if (MODE == 0) {
+            const unsigned char *p = feats + (size_t)f * 144 + 16 + part * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                v[q] = p[q];
+        } else {
+            const double *p = reinterpret_cast<const double *>(feats + (size_t)f * 1120 + 88) + part * 4;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const double d = p[q];
+                ok = ok && d >= 0.0 && d <= 255.0 && d == floor(d);
+                v[q] = ok ? (int)d : 128;
+            }
+        }
+    }
+    int sq = 0;
+    unsigned int packed = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int s = v[q] - 128;
+        sq += s * s;
+        packed |= (unsigned int)(s & 0xff) << (8 * q);
+    }
+    reinterpret_cast<unsigned int *>(rows + (size_t)f * 128)[part] = packed;
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1)
+        sq += __shfl_xor(sq, d, 32);
+    if (part == 0)
+        norms[f] = f < n ? sq : kMatchPadNorm;
+    if (!ok)
+        atomicOr(bad, 1u);
+}
+
+// ---- matching ------------------------------------------------------------------------------------------
+// One wave per 32 features of image 1.  They are the B operand (columns) of every MFMA, loaded once; the
+// features of image 2 stream through as the A operand, 32 at a time, four K-steps of 32 bytes each.  In the
+// 32x32 result lane l holds column l&31 -- one feature of image 1 -- and 16 rows (features of image 2):
+// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Both lane halves of a column keep a running (smallest, its index,
+// second smallest) of  e = |b'|^2 - 2 a'.b'  (|a'|^2 is the same for every candidate and is added at the end);
+// a lane meets its rows in ascending index order, so a strict < keeps the first index, and the two halves
+// are merged by (value, index) at the end.  The ratio test is evaluated in double exactly as the demo
+// does: sqrt(d1) / sqrt(d2) < ratio, with the second distance infinite when image 2 has one feature.
+__global__ __launch_bounds__(64) void match_k(const signed char *rows1, const int *norms1, unsigned int n1,
+                                              const signed char *rows2, const int *norms2, unsigned int n2,
+                                              unsigned int n2_pad, double ratio, int *index2, unsigned int *dist2)
+{
+    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const unsigned int i = blockIdx.x * 32u + r; // rows1 is padded to a multiple of 32
+    v4i bfrag[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+        bfrag[ks] = *reinterpret_cast<const v4i *>(rows1 + (size_t)i * 128 + ks * 32 + h * 16);
+    int m1 = 0x7fffffff, m2 = 0x7fffffff, idx = 0;
+    v4i afrag[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+        afrag[ks] = *reinterpret_cast<const v4i *>(rows2 + (size_t)r * 128 + ks * 32 + h * 16);
+    for (unsigned int jb = 0; jb < n2_pad; jb += 32) {
+        v16i acc;
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            acc[q] = 0;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], bfrag[ks], acc, 0, 0, 0);
+        // next block of image-2 features while the epilogue runs
+        if (jb + 32 < n2_pad) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                afrag[ks] = *reinterpret_cast<const v4i *>(rows2 + (size_t)(jb + 32 + r) * 128 + ks * 32 + h * 16);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int4 cj = *reinterpret_cast<const int4 *>(norms2 + jb + 8 * g + 4 * h);
+            const int c[4] = {cj.x, cj.y, cj.z, cj.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int e = c[q] - 2 * acc[4 * g + q];
+                const int j = (int)jb + 8 * g + 4 * h + q;
+                m2 = min(m2, max(m1, e));
+                idx = e < m1 ? j : idx;
+                m1 = min(m1, e);
+            }
+        }
+    }
+    // merge the two halves of the column
+    const int o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32), oi = __shfl_xor(idx, 32);
+    const bool mine = m1 < o1 || (m1 == o1 && idx < oi);
+    const int b1 = mine ? m1 : o1, bi = mine ? idx : oi;
+    const int b2 = mine ? min(m2, o1) : min(o2, m1);
+    if (h == 0 && i < n1) {
+        int res = -1;
+        unsigned int d1 = 0xffffffffu, d2 = 0xffffffffu;
+        if (n2 >= 1) {
+            const int ci = norms1[i];
+            d1 = (unsigned int)(b1 + ci);
+            const double min_value = sqrt((double)d1);
+            double pen_value = 1.7976931348623157e308; // DBL_MAX, the demo's initial value (源.cpp:102)
+            if (n2 >= 2) {
+                d2 = (unsigned int)(b2 + ci);
+                pen_value = sqrt((double)d2);
+            }
+            if (min_value / pen_value < ratio)
+                res = bi;
+        }
+        index2[i] = res;
+        if (dist2) {
+            dist2[2 * (size_t)i] = d1;
+            dist2[2 * (size_t)i + 1] = d2;
+        }
+    }
+}
+
+void launch_match_prep(const void *feats, int mode, unsigned int n, unsigned int n_pad, signed char *rows, int *norms,
+                       unsigned int *bad, hipStream_t s)
+{
+    if (n_pad == 0)
+        return;
+    const unsigned int blocks = (n_pad + 7) / 8;
+    if (mode == 0)
+        match_prep_k<0><<<blocks, 256, 0, s>>>((const unsigned char *)feats, n, n_pad, rows, norms, bad);
+    else
+        match_prep_k<1><<<blocks, 256, 0, s>>>((const unsigned char *)feats, n, n_pad, rows, norms, bad);
+}
+
+void launch_match(const signed char *rows1, const int *norms1, unsigned int n1, const signed char *rows2,
+                  const int *norms2, unsigned int n2, double ratio, int *index2, unsigned int *dist2, hipStream_t s)
+{
+    if (n1 == 0)
+        return;
+    const unsigned int n2_pad = (n2 + 31) / 32 * 32;
+    match_k<<<(n1 + 31) / 32, 64, 0, s>>>(rows1, norms1, n1, rows2, norms2, n2, n2_pad, ratio, index2, dist2);
+}
+
+} // namespace sg

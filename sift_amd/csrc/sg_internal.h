@@ -129,4 +129,11 @@ void launch_pack(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_s
                  const unsigned int *rank, size_t rank_img_stride, void *out, size_t out_img_stride,
                  unsigned int out_cap, unsigned int *out_counts, unsigned int *overflow, int mode, int sorted,
                  unsigned int cap, int B, hipStream_t s);
+// descriptor matching (kernels_match.hip).  rows: n_pad x 128 signed bytes (value - 128), norms: n_pad squared norms;
+// n_pad = n rounded up to 32 (at least 32).  mode 0: sg_packed_feature records, 1: sg_keypoint records.
+void launch_match_prep(const void *feats, int mode, unsigned int n, unsigned int n_pad, signed char *rows, int *norms,
+                       unsigned int *bad, hipStream_t s);
+void launch_match(const signed char *rows1, const int *norms1, unsigned int n1, const signed char *rows2,
+                  const int *norms2, unsigned int n2, double ratio, int *index2, unsigned int *dist2, hipStream_t s);
+
 } // namespace sg

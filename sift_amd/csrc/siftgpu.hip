@@ -44,6 +44,11 @@ struct sg_ctx {
     int B = 1;
     size_t esize = 8;
     unsigned int feat_cap = 0, cand_cap = 0;
+    // descriptor matching scratch (grown on demand): signed-byte rows and squared norms of the two feature sets
+    signed char *d_mrows[2] = {nullptr, nullptr};
+    int *d_mnorm[2] = {nullptr, nullptr};
+    unsigned int m_cap[2] = {0, 0};
+    unsigned int *d_mbad = nullptr;
 
     // geometry of the current call
     int w = 0, h = 0, octaves = 0, last_batch = 0;
@@ -594,6 +599,10 @@ int sg_destroy(sg_ctx *c)
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
+    void *mbufs[] = {c->d_mrows[0], c->d_mrows[1], c->d_mnorm[0], c->d_mnorm[1], c->d_mbad};
+    for (void *b : mbufs)
+        if (b)
+            (void)hipFree(b);
     if (c->ev.created)
         for (int i = 0; i < kEventPairs; i++) {
             (void)hipEventDestroy(c->ev.start[i]);
@@ -1032,6 +1041,120 @@ int sg_memcpy_d2h(sg_ctx *c, void *dst, const void *d_src, size_t bytes)
     HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return SG_OK;
+}
+
+// ---- descriptor matching (demo main, sift/源.cpp:88-156) ----
+
+static unsigned int match_pad(size_t n) { return n == 0 ? 32u : (unsigned int)((n + 31) / 32 * 32); }
+
+// Makes room for n features in scratch set `which` and fills it from `feats` (device records of the given mode).
+static int match_prepare(sg_ctx *c, int which, const void *d_feats, int mode, size_t n)
+{
+    const unsigned int n_pad = match_pad(n);
+    if (n_pad > c->m_cap[which]) {
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (c->d_mrows[which])
+            (void)hipFree(c->d_mrows[which]);
+        if (c->d_mnorm[which])
+            (void)hipFree(c->d_mnorm[which]);
+        c->d_mrows[which] = nullptr;
+        c->d_mnorm[which] = nullptr;
+        c->m_cap[which] = 0;
+        HIPCHK(c, hipMalloc((void **)&c->d_mrows[which], (size_t)n_pad * 128));
+        HIPCHK(c, hipMalloc((void **)&c->d_mnorm[which], (size_t)n_pad * sizeof(int)));
+        c->m_cap[which] = n_pad;
+    }
+    if (!c->d_mbad) {
+        HIPCHK(c, hipMalloc((void **)&c->d_mbad, sizeof(unsigned int)));
+        HIPCHK(c, hipMemsetAsync(c->d_mbad, 0, sizeof(unsigned int), c->stream));
+    }
+    launch_match_prep(d_feats, mode, (unsigned int)n, n_pad, c->d_mrows[which], c->d_mnorm[which], c->d_mbad, c->stream);
+    return SG_OK;
+}
+
+int sg_match_packed_device(sg_ctx *c, const sg_packed_feature *d_f1, uint32_t n1, const sg_packed_feature *d_f2,
+                           uint32_t n2, double ratio, int32_t *d_index2, uint32_t *d_dist2)
+{
+    if (!c || (n1 && (!d_f1 || !d_index2)) || (n2 && !d_f2))
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    int rc = match_prepare(c, 0, d_f1, 0, n1);
+    if (rc != SG_OK)
+        return rc;
+    rc = match_prepare(c, 1, d_f2, 0, n2);
+    if (rc != SG_OK)
+        return rc;
+    launch_match(c->d_mrows[0], c->d_mnorm[0], n1, c->d_mrows[1], c->d_mnorm[1], n2, ratio, d_index2, d_dist2, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return SG_OK;
+}
+
+int sg_match(sg_ctx *c, const sg_keypoint *f1, size_t n1, const sg_keypoint *f2, size_t n2, double ratio,
+             sg_match_point *out, size_t cap, size_t *n)
+{
+    if (!c || !n || (n1 && !f1) || (n2 && !f2) || (cap && !out) || n1 > 0x7fffffffu || n2 > 0x7fffffffu)
+        return SG_E_INVALID;
+    *n = 0;
+    if (n1 == 0)
+        return SG_OK;
+    (void)hipSetDevice(c->prm.device);
+    hipStream_t s = c->stream;
+    sg_keypoint *d_f = nullptr;
+    int *d_idx = nullptr;
+    const size_t nmax = n1 > n2 ? n1 : n2;
+    int rc = SG_OK;
+    std::vector<int> idx(n1);
+    unsigned int bad = 0;
+    do {
+        if (hipMalloc((void **)&d_f, sizeof(sg_keypoint) * nmax) != hipSuccess ||
+            hipMalloc((void **)&d_idx, sizeof(int) * n1) != hipSuccess) {
+            rc = fail(c, SG_E_HIP, "hipMalloc failed (matching)");
+            break;
+        }
+        // the two record sets pass through one staging buffer, one after the other
+        if (hipMemcpyAsync(d_f, f1, sizeof(sg_keypoint) * n1, hipMemcpyHostToDevice, s) != hipSuccess) {
+            rc = fail(c, SG_E_HIP, "upload failed (matching)");
+            break;
+        }
+        if ((rc = match_prepare(c, 0, d_f, 1, n1)) != SG_OK)
+            break;
+        if (n2 && hipMemcpyAsync(d_f, f2, sizeof(sg_keypoint) * n2, hipMemcpyHostToDevice, s) != hipSuccess) {
+            rc = fail(c, SG_E_HIP, "upload failed (matching)");
+            break;
+        }
+        if ((rc = match_prepare(c, 1, d_f, 1, n2)) != SG_OK)
+            break;
+        launch_match(c->d_mrows[0], c->d_mnorm[0], (unsigned int)n1, c->d_mrows[1], c->d_mnorm[1], (unsigned int)n2,
+                     ratio, d_idx, nullptr, s);
+        if (hipMemcpyAsync(idx.data(), d_idx, sizeof(int) * n1, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(&bad, c->d_mbad, sizeof bad, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(c, SG_E_HIP, "matching failed");
+            break;
+        }
+    } while (0);
+    if (d_f)
+        (void)hipFree(d_f);
+    if (d_idx)
+        (void)hipFree(d_idx);
+    if (rc != SG_OK)
+        return rc;
+    if (bad) {
+        (void)hipMemsetAsync(c->d_mbad, 0, sizeof(unsigned int), s);
+        return fail(c, SG_E_INVALID, "descriptor values must be integers in 0..255");
+    }
+    size_t m = 0;
+    for (size_t i = 0; i < n1; i++) {
+        if (idx[i] < 0)
+            continue;
+        if (m < cap) {
+            out[m].index_1 = (int)i;
+            out[m].index_2 = idx[i];
+        }
+        m++;
+    }
+    *n = m;
+    return m > cap ? SG_E_CAPACITY : SG_OK;
 }
 
 int sg_synth_vnoise5(sg_ctx *c, uint8_t *d_dst, int width, int height, uint64_t seed)

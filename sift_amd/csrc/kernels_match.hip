@@ -67,30 +67,54 @@ __global__ __launch_bounds__(256) void match_prep_k(const unsigned char *feats, 
 }
 
 // ---- matching ------------------------------------------------------------------------------------------
-// One wave per 32 features of image 1.  They are the B operand (columns) of every MFMA, loaded once; the
-// features of image 2 stream through as the A operand, 32 at a time, four K-steps of 32 bytes each.  In the
-// 32x32 result lane l holds column l&31 -- one feature of image 1 -- and 16 rows (features of image 2):
-// row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Both lane halves of a column keep a running (smallest, its index,
-// second smallest) of  e = |b'|^2 - 2 a'.b'  (|a'|^2 is the same for every candidate and is added at the end);
-// a lane meets its rows in ascending index order, so a strict < keeps the first index, and the two halves
-// are merged by (value, index) at the end.  The ratio test is evaluated in double exactly as the demo
-// does: sqrt(d1) / sqrt(d2) < ratio, with the second distance infinite when image 2 has one feature.
-__global__ __launch_bounds__(64) void match_k(const signed char *rows1, const int *norms1, unsigned int n1,
-                                              const signed char *rows2, const int *norms2, unsigned int n2,
-                                              unsigned int n2_pad, double ratio, int *index2, unsigned int *dist2)
+// One workgroup of kMatchWaves waves per 32 features of image 1.  They are the B operand (columns) of every MFMA,
+// loaded once; the features of image 2 stream through as the A operand, 32 at a time (wave w takes blocks
+// w, w + kMatchWaves, ...), four K-steps of 32 bytes each.  In the 32x32 result lane l holds column l&31 -- one feature of
+// image 1 -- and 16 rows (features of image 2): row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Every lane keeps a
+// running (smallest, its index, second smallest) of  e = |b'|^2 - 2 a'.b'  (|a'|^2 is the same for every
+// candidate and is added at the end); a lane meets its rows in ascending index order, so a strict < keeps the
+// first index, and the partial results of a column (two lane halves per wave) are merged by
+// (value, index) at the end.  The ratio test is evaluated in double exactly as the demo does:
+// sqrt(d1) / sqrt(d2) < ratio, with the second distance infinite when image 2 has one feature.
+constexpr int kMatchWaves = 8;
+
+struct MatchBest {
+    int m1, idx, m2;
+};
+
+__device__ __forceinline__ MatchBest match_merge(const MatchBest &a, const MatchBest &b)
 {
-    const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
+    const bool first = a.m1 < b.m1 || (a.m1 == b.m1 && a.idx < b.idx);
+    MatchBest r;
+    r.m1 = first ? a.m1 : b.m1;
+    r.idx = first ? a.idx : b.idx;
+    r.m2 = first ? min(a.m2, b.m1) : min(b.m2, a.m1);
+    return r;
+}
+
+__global__ __launch_bounds__(64 * kMatchWaves) void match_k(const signed char *__restrict__ rows1,
+                                                            const int *__restrict__ norms1, unsigned int n1,
+                                                            const signed char *__restrict__ rows2,
+                                                            const int *__restrict__ norms2, unsigned int n2,
+                                                            unsigned int n2_pad, double ratio, int *__restrict__ index2,
+                                                            unsigned int *__restrict__ dist2)
+{
+    __shared__ MatchBest part[kMatchWaves][32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const unsigned int i = blockIdx.x * 32u + r; // rows1 is padded to a multiple of 32
     v4i bfrag[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ks++)
         bfrag[ks] = *reinterpret_cast<const v4i *>(rows1 + (size_t)i * 128 + ks * 32 + h * 16);
-    int m1 = 0x7fffffff, m2 = 0x7fffffff, idx = 0;
+    MatchBest best = {0x7fffffff, 0, 0x7fffffff};
     v4i afrag[4];
+    unsigned int jb = 32u * wave;
+    if (jb < n2_pad) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++)
-        afrag[ks] = *reinterpret_cast<const v4i *>(rows2 + (size_t)r * 128 + ks * 32 + h * 16);
-    for (unsigned int jb = 0; jb < n2_pad; jb += 32) {
+        for (int ks = 0; ks < 4; ks++)
+            afrag[ks] = *reinterpret_cast<const v4i *>(rows2 + (size_t)(jb + r) * 128 + ks * 32 + h * 16);
+    }
+    for (; jb < n2_pad; jb += 32u * kMatchWaves) {
         v16i acc;
 #pragma unroll
         for (int q = 0; q < 16; q++)
@@ -98,11 +122,12 @@ __global__ __launch_bounds__(64) void match_k(const signed char *rows1, const in
 #pragma unroll
         for (int ks = 0; ks < 4; ks++)
             acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], bfrag[ks], acc, 0, 0, 0);
-        // next block of image-2 features while the epilogue runs
-        if (jb + 32 < n2_pad) {
+        // this wave's next block of image-2 features while the epilogue runs
+        const unsigned int jn = jb + 32u * kMatchWaves;
+        if (jn < n2_pad) {
 #pragma unroll
             for (int ks = 0; ks < 4; ks++)
-                afrag[ks] = *reinterpret_cast<const v4i *>(rows2 + (size_t)(jb + 32 + r) * 128 + ks * 32 + h * 16);
+                afrag[ks] = *reinterpret_cast<const v4i *>(rows2 + (size_t)(jn + r) * 128 + ks * 32 + h * 16);
         }
 #pragma unroll
         for (int g = 0; g < 4; g++) {
@@ -112,31 +137,38 @@ __global__ __launch_bounds__(64) void match_k(const signed char *rows1, const in
             for (int q = 0; q < 4; q++) {
                 const int e = c[q] - 2 * acc[4 * g + q];
                 const int j = (int)jb + 8 * g + 4 * h + q;
-                m2 = min(m2, max(m1, e));
-                idx = e < m1 ? j : idx;
-                m1 = min(m1, e);
+                best.m2 = min(best.m2, max(best.m1, e));
+                best.idx = e < best.m1 ? j : best.idx;
+                best.m1 = min(best.m1, e);
             }
         }
     }
-    // merge the two halves of the column
-    const int o1 = __shfl_xor(m1, 32), o2 = __shfl_xor(m2, 32), oi = __shfl_xor(idx, 32);
-    const bool mine = m1 < o1 || (m1 == o1 && idx < oi);
-    const int b1 = mine ? m1 : o1, bi = mine ? idx : oi;
-    const int b2 = mine ? min(m2, o1) : min(o2, m1);
-    if (h == 0 && i < n1) {
+    // merge the two halves of the column, then the waves
+    MatchBest other;
+    other.m1 = __shfl_xor(best.m1, 32);
+    other.m2 = __shfl_xor(best.m2, 32);
+    other.idx = __shfl_xor(best.idx, 32);
+    best = match_merge(best, other);
+    if (h == 0)
+        part[wave][r] = best;
+    __syncthreads();
+    if (wave == 0 && h == 0 && i < n1) {
+#pragma unroll
+        for (int w = 1; w < kMatchWaves; w++)
+            best = match_merge(best, part[w][r]);
         int res = -1;
         unsigned int d1 = 0xffffffffu, d2 = 0xffffffffu;
         if (n2 >= 1) {
             const int ci = norms1[i];
-            d1 = (unsigned int)(b1 + ci);
+            d1 = (unsigned int)(best.m1 + ci);
             const double min_value = sqrt((double)d1);
             double pen_value = 1.7976931348623157e308; // DBL_MAX, the demo's initial value (源.cpp:102)
             if (n2 >= 2) {
-                d2 = (unsigned int)(b2 + ci);
+                d2 = (unsigned int)(best.m2 + ci);
                 pen_value = sqrt((double)d2);
             }
             if (min_value / pen_value < ratio)
-                res = bi;
+                res = best.idx;
         }
         index2[i] = res;
         if (dist2) {
@@ -164,7 +196,7 @@ void launch_match(const signed char *rows1, const int *norms1, unsigned int n1, 
     if (n1 == 0)
         return;
     const unsigned int n2_pad = (n2 + 31) / 32 * 32;
-    match_k<<<(n1 + 31) / 32, 64, 0, s>>>(rows1, norms1, n1, rows2, norms2, n2, n2_pad, ratio, index2, dist2);
+    match_k<<<(n1 + 31) / 32, 64 * kMatchWaves, 0, s>>>(rows1, norms1, n1, rows2, norms2, n2, n2_pad, ratio, index2, dist2);
 }
 
 } // namespace sg

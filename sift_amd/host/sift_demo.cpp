@@ -51,8 +51,8 @@ static Mat make_image(int w, int h, uint64_t seed)
 
 int main(int argc, char **argv)
 {
-    if (argc != 7) {
-        std::fprintf(stderr, "usage: %s width height seed1 seed2 out1.txt out2.txt\n", argv[0]);
+    if (argc != 7 && argc != 8) {
+        std::fprintf(stderr, "usage: %s width height seed1 seed2 out1.txt out2.txt [matches.txt]\n", argv[0]);
         return 2;
     }
     int w = std::atoi(argv[1]), h = std::atoi(argv[2]);
@@ -81,5 +81,22 @@ int main(int argc, char **argv)
         return 1;
     }
     std::printf("features1 %zu features2 %zu\n", features1.size(), features2.size());
+
+    // the matching loop of the reference's main (sift/源.cpp:88-163)
+    std::vector<MatchPoint> v_matchpoint;
+    MatchFeatures(features1, features2, v_matchpoint);
+    if (SiftLastStatus() != 0) {
+        std::fprintf(stderr, "MatchFeatures failed: %s\n", SiftLastError());
+        return 1;
+    }
+    std::printf("match number: %zu\n", v_matchpoint.size());
+    if (argc == 8) {
+        std::FILE *f = std::fopen(argv[7], "w");
+        if (!f)
+            return 1;
+        for (const MatchPoint &m : v_matchpoint)
+            std::fprintf(f, "%d %d\n", m.index_1, m.index_2);
+        std::fclose(f);
+    }
     return 0;
 }

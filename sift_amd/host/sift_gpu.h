@@ -103,6 +103,14 @@ void Sift_nointerval(const Mat &src, std::vector<Keypoint> &features, double sig
 void read_features(std::vector<Keypoint> &features, const char *file);
 void write_features(const std::vector<Keypoint> &features, const char *file);
 
+// ---- matching: the loop of the reference's demo (sift/源.cpp:88-156) as a function --------------------------
+// For every feature of features1 the nearest and second nearest feature of features2 by Euclidean distance over
+// the descriptor; a MatchPoint is appended when nearest / second nearest < ratio (0.5 in the demo).  Distances
+// are formed per pair (the demo's distance variable carries over between candidates, 源.cpp:97-110; that is not
+// reproduced).  Output in index_1 order.
+void MatchFeatures(const std::vector<Keypoint> &features1, const std::vector<Keypoint> &features2,
+                   std::vector<MatchPoint> &matches, double ratio = 0.5);
+
 // ---- additions of this implementation -----------------------------------------------------------------------
 int SiftLastStatus();            // sg_status of the most recent call on this thread (0 = ok)
 const char *SiftLastError();     // text for it

@@ -523,6 +523,28 @@ void read_features(std::vector<Keypoint> &features, const char *file)
     set_status(SG_OK);
 }
 
+// sift/源.cpp:88-156 (the demo's matching loop); appends to `matches`
+void MatchFeatures(const std::vector<Keypoint> &features1, const std::vector<Keypoint> &features2,
+                   std::vector<MatchPoint> &matches, double ratio)
+{
+    if (features1.empty()) {
+        set_status(SG_OK);
+        return;
+    }
+    sg_ctx *ctx = tls.ctx ? tls.ctx : context_for(2, 2, SIGMA, 0);
+    if (!ctx)
+        return;
+    static_assert(sizeof(MatchPoint) == sizeof(sg_match_point), "MatchPoint layout");
+    std::vector<MatchPoint> found(features1.size());
+    size_t n = 0;
+    int rc = sg_match(ctx, reinterpret_cast<const sg_keypoint *>(features1.data()), features1.size(),
+                      reinterpret_cast<const sg_keypoint *>(features2.data()), features2.size(), ratio,
+                      reinterpret_cast<sg_match_point *>(found.data()), found.size(), &n);
+    set_status(rc, rc == SG_OK ? nullptr : sg_last_error(ctx));
+    if (rc == SG_OK)
+        matches.insert(matches.end(), found.begin(), found.begin() + n);
+}
+
 // sift/sift.cpp:1910-1931: default stream formatting, a line break before every 20th descriptor value
 void write_features(const std::vector<Keypoint> &features, const char *file)
 {

@@ -124,3 +124,42 @@ def test_no_cpu_fallback_without_device():
         pytest.skip("a GPU is present")
     with pytest.raises(sift_amd.SiftGpuError):
         sift_amd.SiftGPU()
+
+
+def test_match_known_answer(oracle):
+    """The demo's matching loop (sift/源.cpp:88-156) on hand-made descriptors."""
+    import numpy as np
+    from oracle.oracle import KEYPOINT_DTYPE
+    f1 = np.zeros(2, dtype=KEYPOINT_DTYPE)
+    f2 = np.zeros(4, dtype=KEYPOINT_DTYPE)
+    f1["descriptor"][0, :4] = [10, 0, 0, 0]
+    f1["descriptor"][1, :4] = [0, 50, 0, 0]
+    f2["descriptor"][0, :4] = [13, 4, 0, 0]    # distance 5 from f1[0]
+    f2["descriptor"][1, :4] = [10, 0, 12, 5]   # distance 13 from f1[0]
+    f2["descriptor"][2, :4] = [0, 47, 4, 0]    # distance 5 from f1[1]
+    f2["descriptor"][3, :4] = [0, 50, 6, 0]    # distance 6 from f1[1]: ratio 5/6 fails 0.5
+    pairs, best2 = oracle.match(f1, f2, 0.5)
+    assert pairs.tolist() == [[0, 0]]
+    assert best2[0].tolist() == [25.0, 169.0]
+    assert best2[1].tolist() == [25.0, 36.0]
+    assert oracle.match(f1, f2, 0.9)[0].tolist() == [[0, 0], [1, 2]]
+    # ties: the first index wins, and the second smallest equals the smallest (ratio 1)
+    f2["descriptor"][1] = f2["descriptor"][0]
+    assert oracle.match(f1[:1], f2, 1.01)[0].tolist() == [[0, 0]]
+    assert oracle.match(f1[:1], f2, 1.0)[0].tolist() == []
+    # one candidate only: the second distance stays DBL_MAX and the ratio test passes
+    assert oracle.match(f1[:1], f2[:1], 0.5)[0].tolist() == [[0, 0]]
+    assert oracle.match(f1[:1], f2[:0], 0.5)[0].tolist() == []
+
+
+def test_match_demo_accumulation_differs(oracle):
+    """The demo never resets its distance variable (源.cpp:97-110); the literal form sees sqrt(previous + d^2)."""
+    import numpy as np
+    from oracle.oracle import KEYPOINT_DTYPE
+    f1 = np.zeros(1, dtype=KEYPOINT_DTYPE)
+    f2 = np.zeros(3, dtype=KEYPOINT_DTYPE)
+    f2["descriptor"][0, 0] = 200   # far
+    f2["descriptor"][1, 0] = 3     # near: d = 3; literal form: sqrt(200 + 9) = 14.46
+    f2["descriptor"][2, 0] = 8     # d = 8; literal form: sqrt(14.46 + 64) = 8.86
+    assert oracle.match(f1, f2, 0.5)[0].tolist() == [[0, 1]]                        # 3 / 8 < 0.5
+    assert oracle.match(f1, f2, 0.5, accumulate_bug=True)[0].tolist() == []         # 8.86 / 14.46 > 0.5

@@ -22,9 +22,10 @@ def test_demo_flow_matches_oracle_text(oracle, tmp_path):
     """Sift() and Sift_nointerval() + write_features, as in the reference's main(): the text files equal the
     ones the CPU oracle writes for the same images."""
     exe = _need("sift_demo")
-    w, h, s1, s2 = 200, 150, 1234, 4321
-    o1, o2 = str(tmp_path / "d1.txt"), str(tmp_path / "d2.txt")
-    out = subprocess.run([exe, str(w), str(h), str(s1), str(s2), o1, o2], capture_output=True, text=True, timeout=120)
+    w, h, s1, s2 = 200, 150, 1234, 1234  # the same scene through both detectors, so that matches exist
+    o1, o2, om = str(tmp_path / "d1.txt"), str(tmp_path / "d2.txt"), str(tmp_path / "m.txt")
+    out = subprocess.run([exe, str(w), str(h), str(s1), str(s2), o1, o2, om], capture_output=True, text=True,
+                         timeout=120)
     assert out.returncode == 0, out.stderr
     f1, _, _, _ = oracle.sift(oracle.vnoise5(w, h, s1))
     f2, _, _, _ = oracle.sift(oracle.vnoise5(w, h, s2), nointerval=True)
@@ -34,6 +35,11 @@ def test_demo_flow_matches_oracle_text(oracle, tmp_path):
     assert open(o1, "rb").read() == open(r1, "rb").read()
     assert open(o2, "rb").read() == open(r2, "rb").read()
     assert "features1 %d features2 %d" % (len(f1), len(f2)) in out.stdout
+    # MatchFeatures (the demo's matching loop) against the oracle's
+    ref, _ = oracle.match(f1, f2, 0.5)
+    got = np.array([[int(v) for v in line.split()] for line in open(om)], dtype=np.int32).reshape(-1, 2)
+    assert len(ref) > 20 and np.array_equal(got, ref)
+    assert "match number: %d" % len(ref) in out.stdout
 
 
 def test_stage_entry_points_equal_driver():

@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void match_prep_k(const unsigned char *feats, 
 }
 
 // ---- matching ------------------------------------------------------------------------------------------
-// One workgroup of kMatchWaves waves per 32 features of image 1.  They are the B operand (columns) of every MFMA,
+// One workgroup of kMatchWaves waves per kMatchGroups x 32 features of image 1.  They are the B operands (columns) of the MFMAs,
 // loaded once; the features of image 2 stream through as the A operand, 32 at a time (wave w takes blocks
 // w, w + kMatchWaves, ...), four K-steps of 32 bytes each.  In the 32x32 result lane l holds column l&31 -- one feature of
 // image 1 -- and 16 rows (features of image 2): row = (reg&3) + 8*(reg>>2) + 4*(l>>5).  Every lane keeps a
@@ -77,6 +77,11 @@ __global__ __launch_bounds__(256) void match_prep_k(const unsigned char *feats, 
 // (value, index) at the end.  The ratio test is evaluated in double exactly as the demo does:
 // sqrt(d1) / sqrt(d2) < ratio, with the second distance infinite when image 2 has one feature.
 constexpr int kMatchWaves = 8;
+#ifndef SG_MATCH_GROUPS
+#define SG_MATCH_GROUPS 4
+#endif
+constexpr int kMatchGroups = SG_MATCH_GROUPS; // groups of 32 image-1 features per workgroup
+static_assert(kMatchGroups <= kMatchWaves, "one wave finishes each group");
 
 struct MatchBest {
     int m1, idx, m2;
@@ -94,19 +99,29 @@ __device__ __forceinline__ MatchBest match_merge(const MatchBest &a, const Match
 
 __global__ __launch_bounds__(64 * kMatchWaves) void match_k(const signed char *__restrict__ rows1,
                                                             const int *__restrict__ norms1, unsigned int n1,
-                                                            const signed char *__restrict__ rows2,
+                                                            unsigned int n1_pad, const signed char *__restrict__ rows2,
                                                             const int *__restrict__ norms2, unsigned int n2,
                                                             unsigned int n2_pad, double ratio, int *__restrict__ index2,
                                                             unsigned int *__restrict__ dist2)
 {
-    __shared__ MatchBest part[kMatchWaves][32];
+    __shared__ MatchBest part[kMatchWaves][kMatchGroups][32];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
-    const unsigned int i = blockIdx.x * 32u + r; // rows1 is padded to a multiple of 32
-    v4i bfrag[4];
+    // kMatchGroups groups of 32 image-1 features per workgroup: every block of image-2 features a wave loads serves
+    // all of them (the image-2 matrix is streamed n1 / (32 * kMatchGroups) times in all)
+    v4i bfrag[kMatchGroups][4];
+    unsigned int i_of[kMatchGroups];
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++)
-        bfrag[ks] = *reinterpret_cast<const v4i *>(rows1 + (size_t)i * 128 + ks * 32 + h * 16);
-    MatchBest best = {0x7fffffff, 0, 0x7fffffff};
+    for (int g = 0; g < kMatchGroups; g++) {
+        i_of[g] = min((blockIdx.x * kMatchGroups + g) * 32u + r, n1_pad - 1); // groups past the end repeat the last row
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+            bfrag[g][ks] = *reinterpret_cast<const v4i *>(rows1 + (size_t)i_of[g] * 128 + ks * 32 + h * 16);
+    }
+    MatchBest best[kMatchGroups];
+#pragma unroll
+    for (int g = 0; g < kMatchGroups; g++)
+        best[g] = MatchBest{0x7fffffff, 0, 0x7fffffff};
+    constexpr unsigned int kStep = 32u * kMatchWaves;
     v4i afrag[4];
     unsigned int jb = 32u * wave;
     if (jb < n2_pad) {
@@ -114,66 +129,79 @@ __global__ __launch_bounds__(64 * kMatchWaves) void match_k(const signed char *_
         for (int ks = 0; ks < 4; ks++)
             afrag[ks] = *reinterpret_cast<const v4i *>(rows2 + (size_t)(jb + r) * 128 + ks * 32 + h * 16);
     }
-    for (; jb < n2_pad; jb += 32u * kMatchWaves) {
-        v16i acc;
+    for (; jb < n2_pad; jb += kStep) {
+        v16i acc[kMatchGroups];
 #pragma unroll
-        for (int q = 0; q < 16; q++)
-            acc[q] = 0;
+        for (int g = 0; g < kMatchGroups; g++) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ks++)
-            acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], bfrag[ks], acc, 0, 0, 0);
-        // this wave's next block of image-2 features while the epilogue runs
-        const unsigned int jn = jb + 32u * kMatchWaves;
-        if (jn < n2_pad) {
+            for (int q = 0; q < 16; q++)
+                acc[g][q] = 0;
 #pragma unroll
             for (int ks = 0; ks < 4; ks++)
-                afrag[ks] = *reinterpret_cast<const v4i *>(rows2 + (size_t)(jn + r) * 128 + ks * 32 + h * 16);
+                acc[g] = __builtin_amdgcn_mfma_i32_32x32x32_i8(afrag[ks], bfrag[g][ks], acc[g], 0, 0, 0);
+        }
+        // this wave's next block of image-2 features while the vector ALU folds the products in
+        if (jb + kStep < n2_pad) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ks++)
+                afrag[ks] = *reinterpret_cast<const v4i *>(rows2 + (size_t)(jb + kStep + r) * 128 + ks * 32 + h * 16);
         }
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-            const int4 cj = *reinterpret_cast<const int4 *>(norms2 + jb + 8 * g + 4 * h);
+        for (int q4 = 0; q4 < 4; q4++) {
+            const int4 cj = *reinterpret_cast<const int4 *>(norms2 + jb + 8 * q4 + 4 * h);
             const int c[4] = {cj.x, cj.y, cj.z, cj.w};
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const int e = c[q] - 2 * acc[4 * g + q];
-                const int j = (int)jb + 8 * g + 4 * h + q;
-                best.m2 = min(best.m2, max(best.m1, e));
-                best.idx = e < best.m1 ? j : best.idx;
-                best.m1 = min(best.m1, e);
+                const int j = (int)jb + 8 * q4 + 4 * h + q;
+#pragma unroll
+                for (int g = 0; g < kMatchGroups; g++) {
+                    const int e = c[q] - 2 * acc[g][4 * q4 + q];
+                    best[g].m2 = min(best[g].m2, max(best[g].m1, e));
+                    best[g].idx = e < best[g].m1 ? j : best[g].idx;
+                    best[g].m1 = min(best[g].m1, e);
+                }
             }
         }
     }
-    // merge the two halves of the column, then the waves
-    MatchBest other;
-    other.m1 = __shfl_xor(best.m1, 32);
-    other.m2 = __shfl_xor(best.m2, 32);
-    other.idx = __shfl_xor(best.idx, 32);
-    best = match_merge(best, other);
-    if (h == 0)
-        part[wave][r] = best;
-    __syncthreads();
-    if (wave == 0 && h == 0 && i < n1) {
+    // merge the two halves of each column, then the waves
 #pragma unroll
-        for (int w = 1; w < kMatchWaves; w++)
-            best = match_merge(best, part[w][r]);
-        int res = -1;
-        unsigned int d1 = 0xffffffffu, d2 = 0xffffffffu;
-        if (n2 >= 1) {
-            const int ci = norms1[i];
-            d1 = (unsigned int)(best.m1 + ci);
-            const double min_value = sqrt((double)d1);
-            double pen_value = 1.7976931348623157e308; // DBL_MAX, the demo's initial value (源.cpp:102)
-            if (n2 >= 2) {
-                d2 = (unsigned int)(best.m2 + ci);
-                pen_value = sqrt((double)d2);
+    for (int g = 0; g < kMatchGroups; g++) {
+        MatchBest other;
+        other.m1 = __shfl_xor(best[g].m1, 32);
+        other.m2 = __shfl_xor(best[g].m2, 32);
+        other.idx = __shfl_xor(best[g].idx, 32);
+        best[g] = match_merge(best[g], other);
+        if (h == 0)
+            part[wave][g][r] = best[g];
+    }
+    __syncthreads();
+    if (wave < kMatchGroups && h == 0) {
+        const int g = wave; // wave g finishes group g
+        const unsigned int i = (blockIdx.x * kMatchGroups + g) * 32u + r;
+        if (i < n1) {
+            MatchBest b = part[0][g][r];
+#pragma unroll
+            for (int w = 1; w < kMatchWaves; w++)
+                b = match_merge(b, part[w][g][r]);
+            int res = -1;
+            unsigned int d1 = 0xffffffffu, d2 = 0xffffffffu;
+            if (n2 >= 1) {
+                const int ci = norms1[i];
+                d1 = (unsigned int)(b.m1 + ci);
+                const double min_value = sqrt((double)d1);
+                double pen_value = 1.7976931348623157e308; // DBL_MAX, the demo's initial value (源.cpp:102)
+                if (n2 >= 2) {
+                    d2 = (unsigned int)(b.m2 + ci);
+                    pen_value = sqrt((double)d2);
+                }
+                if (min_value / pen_value < ratio)
+                    res = b.idx;
             }
-            if (min_value / pen_value < ratio)
-                res = best.idx;
-        }
-        index2[i] = res;
-        if (dist2) {
-            dist2[2 * (size_t)i] = d1;
-            dist2[2 * (size_t)i + 1] = d2;
+            index2[i] = res;
+            if (dist2) {
+                dist2[2 * (size_t)i] = d1;
+                dist2[2 * (size_t)i + 1] = d2;
+            }
         }
     }
 }
@@ -196,7 +224,10 @@ void launch_match(const signed char *rows1, const int *norms1, unsigned int n1, 
     if (n1 == 0)
         return;
     const unsigned int n2_pad = (n2 + 31) / 32 * 32;
-    match_k<<<(n1 + 31) / 32, 64 * kMatchWaves, 0, s>>>(rows1, norms1, n1, rows2, norms2, n2, n2_pad, ratio, index2, dist2);
+    const unsigned int n1_pad = (n1 + 31) / 32 * 32;
+    const unsigned int groups = n1_pad / 32;
+    match_k<<<(groups + kMatchGroups - 1) / kMatchGroups, 64 * kMatchWaves, 0, s>>>(rows1, norms1, n1, n1_pad, rows2, norms2,
+                                                                                    n2, n2_pad, ratio, index2, dist2);
 }
 
 } // namespace sg

@@ -115,17 +115,25 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One GPU per rank.  For a rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks, ranks wrap
+    # around the devices present and SIFT_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU).
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("SIFT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     W, H, B, K, WU = args.width, args.height, args.batch, args.steps, args.warmup
     prec = sift_amd.SG_F64 if args.precision == "f64" else sift_amd.SG_F32
     esize = 8 if prec == sift_amd.SG_F64 else 4
     nctx = max(1, min(args.contexts, 4))
-    ctxs = [sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=B, precision=prec, device=local_rank)
+    ctxs = [sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=B, precision=prec, device=dev_index)
             for _ in range(nctx)]
 
     # ---- synthetic frames, generated on the device, resident in HBM ----
@@ -139,45 +147,53 @@ def main():
     ctxs[0].sync()
 
     cap = args.cap
-    outs = [torch.empty(B * cap * 144, dtype=torch.uint8, device=dev) for _ in range(nctx)]
-    cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nctx)]
+    # Output buffers: one per context; with more than one rank at least two, so that the all-gather of one step's
+    # features never reads a buffer the next step's extraction is writing.
+    nbuf = nctx if world == 1 else max(2, nctx)
+    outs = [torch.empty(B * cap * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
     if world > 1:
-        g_outs = [torch.empty(world * B * cap * 144, dtype=torch.uint8, device=dev) for _ in range(nctx)]
-        g_cnts = [torch.zeros(world * B, dtype=torch.int32, device=dev) for _ in range(nctx)]
-    handles = [None] * nctx
-    pending = [False] * nctx
-    total_feats = [0]
+        g_outs = [torch.empty(world * B * cap * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        g_cnts = [torch.zeros(world * B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    handles = [None] * nbuf      # all-gather in flight on buffer b
+    pending = [None] * nctx      # buffer that context c's batch in flight writes
+
+    def wait_gather(b):
+        """Buffer b's all-gather (if any) has completed when this returns."""
+        if handles[b] is not None:
+            for hnd in handles[b]:
+                hnd.wait()
+            handles[b] = None
+            torch.cuda.current_stream().synchronize()
 
     def retire(c):
         """Wait for context c's batch; hand its features to the all-gather."""
-        if not pending[c]:
+        b = pending[c]
+        if b is None:
             return
         ctxs[c].sync()
-        pending[c] = False
+        pending[c] = None
         if world > 1:
-            _, _, handles[c] = sdist.allgather_features(outs[c], cnts[c], async_op=True, out=g_outs[c],
-                                                        out_counts=g_cnts[c])
+            _, _, handles[b] = sdist.allgather_features(outs[b], cnts[b], async_op=True, out=g_outs[b],
+                                                        out_counts=g_cnts[b])
 
     def submit(step):
-        c = step % nctx
+        c, b = step % nctx, step % nbuf
         retire(c)
-        if handles[c] is not None:
-            for hnd in handles[c]:
-                hnd.wait()
-            handles[c] = None
+        wait_gather(b)
         first = (step * B) % pool
         ctxs[c].extract_batch_device(frames.data_ptr() + first * frame_bytes, B, W, H, 3,
-                                     outs[c].data_ptr(), cap, cnts[c].data_ptr())
-        pending[c] = True
+                                     outs[b].data_ptr(), cap, cnts[b].data_ptr())
+        pending[c] = b
+        last_buf[0] = b
+
+    last_buf = [0]
 
     def drain():
         for c in range(nctx):
             retire(c)
-        for c in range(nctx):
-            if handles[c] is not None:
-                for hnd in handles[c]:
-                    hnd.wait()
-                handles[c] = None
+        for b in range(nbuf):
+            wait_gather(b)
         torch.cuda.synchronize()
 
     def barrier():
@@ -217,7 +233,7 @@ def main():
             stage_ms[k] = stage_ms.get(k, 0.0) + ms
             stage_launches[k] = stage_launches.get(k, 0) + ln
         c.set_profiling(False)
-    feat_counts = cnts[(WU + K - 1) % nctx].cpu().numpy()
+    feat_counts = cnts[last_buf[0]].cpu().numpy()
 
     if rank != 0:
         if world > 1:

@@ -49,6 +49,16 @@ def main():
         small["src_%dx%d" % (ww, hh)] = src
         small["blur27_%dx%d" % (ww, hh)] = O.gaussian_blur(src, 3.0900155872895909)
     np.savez_compressed(os.path.join(HERE, "blur_small_planes.npz"), **small)
+    # matching (the demo's loop after the path): two overlapping crops of one scene
+    w, h, seed, sx, sy = 200, 150, 77, 7, 5
+    big = O.vnoise5(w + sx, h + sy, seed)
+    fa, _, _, _ = O.sift(np.ascontiguousarray(big[:h, :w]))
+    fb, _, _, _ = O.sift(np.ascontiguousarray(big[sy:sy + h, sx:sx + w]))
+    pairs, best2 = O.match(fa, fb, 0.5)
+    pairs8, _ = O.match(fa, fb, 0.8)
+    np.savez_compressed(os.path.join(HERE, "match_200x150_s77.npz"), desc_a=fa["descriptor"].astype(np.uint8),
+                        desc_b=fb["descriptor"].astype(np.uint8), pairs_05=pairs, pairs_08=pairs8,
+                        best2=best2.astype(np.uint32), geometry=np.array([w, h, seed, sx, sy]))
     json.dump(index, open(os.path.join(HERE, "index.json"), "w"), indent=1)
     print("wrote", [c["name"] for c in index])
 

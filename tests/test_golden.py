@@ -62,3 +62,31 @@ def test_gpu_blur_small_planes(gpu64):
     for key in g.files:
         if key.startswith("src_"):
             assert np.array_equal(gpu64.gaussian_smooth(g[key], 3.0900155872895909), g["blur27_" + key[4:]])
+
+
+def _match_fixture():
+    return np.load(os.path.join(GOLD, "match_200x150_s77.npz"))
+
+
+def _records(desc):
+    from oracle.oracle import KEYPOINT_DTYPE
+    f = np.zeros(len(desc), dtype=KEYPOINT_DTYPE)
+    f["descriptor"] = desc
+    f["descr_length"] = 128
+    return f
+
+
+def test_oracle_match_reproduces_golden(oracle):
+    g = _match_fixture()
+    pairs, best2 = oracle.match(_records(g["desc_a"]), _records(g["desc_b"]), 0.5)
+    assert np.array_equal(pairs, g["pairs_05"]) and np.array_equal(best2.astype(np.uint32), g["best2"])
+    assert np.array_equal(oracle.match(_records(g["desc_a"]), _records(g["desc_b"]), 0.8)[0], g["pairs_08"])
+
+
+@pytest.mark.gpu
+def test_gpu_match_reproduces_golden(gpu64):
+    g = _match_fixture()
+    a, b = _records(g["desc_a"]), _records(g["desc_b"])
+    assert len(g["pairs_05"]) > 50
+    assert np.array_equal(gpu64.match(a, b, 0.5), g["pairs_05"])
+    assert np.array_equal(gpu64.match(a, b, 0.8), g["pairs_08"])

@@ -229,3 +229,35 @@ def test_ragged_sizes_match_oracle(oracle, gpu64, w, h, seed):
     for f in FIELDS_EXACT:
         assert np.array_equal(got[f], ref[f]), f
     assert np.array_equal(got["descriptor"], ref["descriptor"])
+
+
+def test_context_reuse_across_sizes_and_batches(oracle):
+    """One context, a sequence of different image sizes and batch sizes: every result equals the oracle's and a
+    repeated input gives the same bytes again (no state carried from a larger geometry into a smaller one)."""
+    import sift_amd
+    sizes = [(320, 240, 7), (96, 64, 1), (640, 480, 3), (131, 77, 3), (320, 240, 7)]
+    refs = {}
+    with sift_amd.SiftGPU(max_width=640, max_height=480, max_batch=3) as ctx:
+        first = None
+        for w, h, seed in sizes:
+            img = oracle.vnoise5(w, h, seed)
+            if (w, h, seed) not in refs:
+                refs[(w, h, seed)] = oracle.sift(img)[0]
+            ref = refs[(w, h, seed)]
+            got = ctx.extract(img)
+            assert len(got) == len(ref), (w, h)
+            assert np.array_equal(got["descriptor"], ref["descriptor"]), (w, h)
+            assert np.array_equal(got["x"], ref["x"]) and np.array_equal(got["y"], ref["y"])
+            if (w, h, seed) == sizes[0]:
+                if first is None:
+                    first = got
+                else:
+                    for f in got.dtype.names:
+                        assert got[f].tobytes() == first[f].tobytes(), f
+        # a batch of three different frames of one size after all that
+        imgs = np.stack([oracle.vnoise5(200, 150, s) for s in (11, 12, 13)])
+        outs = ctx.extract_batch(imgs, 4096)
+        for img, out in zip(imgs, outs):
+            ref = oracle.sift(img)[0]
+            assert len(out) == len(ref)
+            assert np.array_equal(out["desc"], ref["descriptor"].astype(np.uint8))

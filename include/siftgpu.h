@@ -74,7 +74,8 @@ typedef struct sg_counters {
 
 /* Defaults are the macros of sift/sift.h:19-70. */
 typedef struct sg_params {
-    double sigma;      /* SIGMA 1.6 */
+    double sigma;      /* SIGMA 1.6; any value > 1 (the base blur is sqrt(sigma^2 - 1), sift.cpp:343): up to 1.68 every blur
+                          runs in the unrolled fused kernels, above that the wide ones take the any-radius kernels */
     int intervals;     /* INTERVALS 3; only 3 is supported (the reference hard-wires the macro at
                           sift.cpp:870,886,1325,1613, so other values are inconsistent there) */
     int precision;     /* sg_precision */

@@ -715,8 +715,8 @@ static Taps<T> padded_taps(const double *taps, int n, int R)
 template <typename T>
 static T *upload_taps(const double *taps, int n, hipStream_t s)
 {
-    T host[1024];
-    if (n > 1024)
+    T host[kMaxAnyTaps];
+    if (n > kMaxAnyTaps)
         return nullptr;
     for (int i = 0; i < n; i++)
         host[i] = (T)taps[i];
@@ -729,7 +729,8 @@ static T *upload_taps(const double *taps, int n, hipStream_t s)
 }
 
 template <typename T, int V, int U>
-static void row_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s)
+static void row_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s,
+                         const void *d_taps)
 {
     const int rows = src.rows, cols = src.cols;
     dim3 g2((cols + 63) / 64, (rows + 3) / 4, B);
@@ -753,18 +754,24 @@ static void row_dispatch(const Plane &src, const Plane &dst, int B, const double
         SG_ROW_CASE(10)
         SG_ROW_CASE(13)
     default: {
-        T *dt = upload_taps<T>(taps, n, s);
-        blur_row_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
-                                             src.img_stride, dst.img_stride, dt, n);
-        hipStreamSynchronize(s);
-        hipFree(dt);
+        if (d_taps) {
+            blur_row_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
+                                                 src.img_stride, dst.img_stride, (const T *)d_taps, n);
+        } else {
+            T *dt = upload_taps<T>(taps, n, s);
+            blur_row_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
+                                                 src.img_stride, dst.img_stride, dt, n);
+            hipStreamSynchronize(s);
+            hipFree(dt);
+        }
     }
     }
 #undef SG_ROW_CASE
 }
 
 template <typename T, int V, int RPT>
-static void col_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s)
+static void col_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s,
+                         const void *d_taps)
 {
     const int rows = src.rows, cols = src.cols;
     dim3 g2((cols + 63) / 64, (rows + 3) / 4, B);
@@ -789,11 +796,16 @@ static void col_dispatch(const Plane &src, const Plane &dst, int B, const double
         SG_COL_CASE(10)
         SG_COL_CASE(13)
     default: {
-        T *dt = upload_taps<T>(taps, n, s);
-        blur_col_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
-                                             src.img_stride, dst.img_stride, dt, n);
-        hipStreamSynchronize(s);
-        hipFree(dt);
+        if (d_taps) {
+            blur_col_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
+                                                 src.img_stride, dst.img_stride, (const T *)d_taps, n);
+        } else {
+            T *dt = upload_taps<T>(taps, n, s);
+            blur_col_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
+                                                 src.img_stride, dst.img_stride, dt, n);
+            hipStreamSynchronize(s);
+            hipFree(dt);
+        }
     }
     }
 #undef SG_COL_CASE
@@ -961,20 +973,22 @@ bool blur_fused_decimates(const Plane &src, int n, int prec)
            !blur_use_ring(bucket_radius(n / 2), prec == SG_F64 ? 8 : 4);
 }
 
-void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s)
+void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+                     const void *d_taps)
 {
     if (prec == SG_F64)
-        row_dispatch<double, 2, 2>(src, dst, B, taps, n, s);
+        row_dispatch<double, 2, 2>(src, dst, B, taps, n, s, d_taps);
     else
-        row_dispatch<float, 4, 1>(src, dst, B, taps, n, s);
+        row_dispatch<float, 4, 1>(src, dst, B, taps, n, s, d_taps);
 }
 
-void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s)
+void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+                     const void *d_taps)
 {
     if (prec == SG_F64)
-        col_dispatch<double, 2, 8>(src, dst, B, taps, n, s);
+        col_dispatch<double, 2, 8>(src, dst, B, taps, n, s, d_taps);
     else
-        col_dispatch<float, 4, 8>(src, dst, B, taps, n, s);
+        col_dispatch<float, 4, 8>(src, dst, B, taps, n, s, d_taps);
 }
 
 } // namespace sg

@@ -13,6 +13,7 @@ constexpr int kLevels = 6;        // INTERVALS + 3 Gaussian levels per octave
 constexpr int kDogLevels = 5;     // INTERVALS + 2
 constexpr int kMaxFastRadius = 13;
 constexpr int kMaxTaps = 2 * kMaxFastRadius + 1;
+constexpr int kMaxAnyTaps = 1024; // widest kernel the any-radius blur takes
 constexpr int kBorder = 5;        // IMG_BORDER, sift.h:58
 constexpr int kChunkWords = 1024; // bitmap words per compaction chunk
 constexpr int kOriBins = 36;
@@ -71,8 +72,12 @@ void launch_vnoise5(uint8_t *dst, int rows, int cols, uint64_t seed, hipStream_t
 
 // ---- blur ---------------------------------------------------------------------------------
 // taps: n doubles (host), n odd. Row pass src->tmp, column pass tmp->dst. In-place (src==dst) is allowed.
-void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
-void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s);
+// d_taps (optional): the n taps already on the device in the plane's type; without it a blur wider than the unrolled
+// kernels uploads them itself (allocating and synchronising)
+void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+                     const void *d_taps = nullptr);
+void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+                     const void *d_taps = nullptr);
 // Row and column pass in one launch (src != dst). Returns false, launching nothing, where only the two-pass
 // kernels apply (1-pixel-wide or -high planes, radius beyond the fast kernels).
 // true when launch_blur_fused handles this plane and tap count (else the two-pass kernels must be used)

@@ -58,8 +58,9 @@ struct sg_ctx {
     unsigned int n_words = 0;
 
     // taps: [0] initial blur, [1..5] pyramid levels
-    double taps[kLevels][kMaxTaps];
+    double taps[kLevels][kMaxAnyTaps]; // Gaussian taps of the base blur (0) and the five pyramid blurs
     int ntaps[kLevels];
+    void *d_taps[kLevels] = {}; // device copies in the pyramid's type, for blurs wider than the unrolled kernels
 
     // device buffers
     uint8_t *d_in = nullptr;
@@ -414,13 +415,14 @@ static bool blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, co
     tmp.img_stride = (size_t)src.rows * src.pitch;
     // With the fused kernel in use the two-pass fallback (tiny planes) is timed under the row slot as a whole,
     // so that the column slot holds the fused kernel's launches only.
+    const void *d_taps = taps == c->taps[slot] ? c->d_taps[slot] : nullptr; // the context's own levels only
     {
         StageScope sc(c, SG_ST_BLUR_ROW0 + slot);
-        launch_blur_row(src, tmp, B, taps, n, c->prm.precision, c->stream);
+        launch_blur_row(src, tmp, B, taps, n, c->prm.precision, c->stream, d_taps);
     }
     {
         StageScope sc(c, (c->fused_blur ? SG_ST_BLUR_ROW0 : SG_ST_BLUR_COL0) + slot);
-        launch_blur_col(tmp, dst, B, taps, n, c->prm.precision, c->stream);
+        launch_blur_col(tmp, dst, B, taps, n, c->prm.precision, c->stream, d_taps);
     }
     return false;
 }
@@ -599,7 +601,8 @@ int sg_destroy(sg_ctx *c)
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
-    void *mbufs[] = {c->d_mrows[0], c->d_mrows[1], c->d_mnorm[0], c->d_mnorm[1], c->d_mbad};
+    void *mbufs[] = {c->d_mrows[0], c->d_mrows[1], c->d_mnorm[0], c->d_mnorm[1], c->d_mbad,
+                     c->d_taps[0], c->d_taps[1], c->d_taps[2], c->d_taps[3], c->d_taps[4], c->d_taps[5]};
     for (void *b : mbufs)
         if (b)
             (void)hipFree(b);
@@ -652,11 +655,15 @@ int sg_create(const sg_params *p, sg_ctx **out)
             sig[i] = sqrt(sig_total * sig_total - sig_prev * sig_prev);
         }
     }
+    if (!(p->sigma > 1.0)) { // the base blur is sqrt(sigma^2 - (2*INIT_SIGMA)^2), sift.cpp:343
+        delete c;
+        return SG_E_UNSUPPORTED;
+    }
     for (int i = 0; i < kLevels; i++) {
-        c->ntaps[i] = gaussian_taps(sig[i], c->taps[i], kMaxTaps);
+        c->ntaps[i] = gaussian_taps(sig[i], c->taps[i], kMaxAnyTaps);
         if (c->ntaps[i] < 0) {
             delete c;
-            return SG_E_UNSUPPORTED; // sigma so large that a pyramid blur exceeds the fast kernels' radius
+            return SG_E_UNSUPPORTED; // more taps than the any-radius kernels take
         }
     }
 
@@ -720,6 +727,17 @@ int sg_create(const sg_params *p, sg_ctx **out)
     ALLOC(c->d_bwork, sizeof(unsigned int) * 2 * kRankBuckets * B);
     ALLOC(c->d_blist, sizeof(unsigned int) * (size_t)c->feat_cap * B);
     ALLOC(c->d_rtot, sizeof(unsigned int) * (B + 1));
+    for (int i = 0; i < kLevels; i++) {
+        if (c->ntaps[i] <= kMaxTaps)
+            continue; // served by the unrolled kernels, taps travel as a kernel argument
+        ALLOC(c->d_taps[i], c->esize * (size_t)c->ntaps[i]);
+        if (c->esize == 8) {
+            (void)hipMemcpy(c->d_taps[i], c->taps[i], sizeof(double) * c->ntaps[i], hipMemcpyHostToDevice);
+        } else {
+            std::vector<float> tf(c->taps[i], c->taps[i] + c->ntaps[i]);
+            (void)hipMemcpy(c->d_taps[i], tf.data(), sizeof(float) * c->ntaps[i], hipMemcpyHostToDevice);
+        }
+    }
 #undef ALLOC
     (void)hipMemset(c->d_words, 0, sizeof(unsigned long long) * c->words_img * B);
     (void)hipMemset(c->d_vwords, 0, sizeof(unsigned long long) * c->vwords_img * B);

@@ -119,8 +119,8 @@ def test_nointerval_variant(oracle):
 def test_wide_windows_through_stage_entry_points(oracle, gpu64, sigma):
     """Keypoints whose orientation / descriptor windows outgrow the common kernels' tables (orientation
     radius >= 64 and descriptor radius > 127 at the larger sigma) go through the wide-window kernel
-    variants.  The pipeline context does not take such base scales, so the oracle's pyramid and keypoints at
-    that sigma are handed to the OrientationAssignment / DescriptorRepresentation entry points."""
+    variants, here through the OrientationAssignment / DescriptorRepresentation entry points on the oracle's pyramid
+    and keypoints at that sigma."""
     img = oracle.vnoise5(256, 192, 5)
     dbg = oracle.Debug(img, sigma=sigma)
     assert len(dbg.features) > 20
@@ -261,3 +261,29 @@ def test_context_reuse_across_sizes_and_batches(oracle):
             ref = oracle.sift(img)[0]
             assert len(out) == len(ref)
             assert np.array_equal(out["desc"], ref["descriptor"].astype(np.uint8))
+
+
+@pytest.mark.parametrize("sigma", [1.2, 2.0, 3.2, 8.0])
+def test_other_base_sigmas(oracle, sigma):
+    """Sift(src, features, sigma) with a sigma other than the default: narrower blurs pad into the unrolled kernels,
+    wider ones take the any-radius kernels (and, at the largest, the wide-window orientation / descriptor variants)."""
+    import sift_amd
+    img = oracle.vnoise5(256, 192, 5)
+    dbg = oracle.Debug(img, sigma=sigma)
+    with sift_amd.SiftGPU(max_width=256, max_height=192, sigma=sigma) as ctx:
+        got = ctx.extract(img)
+        for o in range(dbg.octaves):
+            for l in range(6):
+                assert np.array_equal(ctx.read_level(o, l), dbg.gauss[o * 6 + l]), "octave %d level %d" % (o, l)
+        assert ctx.read_counters() == dbg.counters
+    ref = dbg.sorted_features
+    assert len(ref) > 20 and len(got) == len(ref)
+    for f in FIELDS_EXACT:
+        assert np.array_equal(got[f], ref[f]), f
+    assert np.array_equal(got["descriptor"], ref["descriptor"])
+
+
+def test_sigma_not_above_one_is_rejected():
+    import sift_amd
+    with pytest.raises(sift_amd.SiftGpuError):
+        sift_amd.SiftGPU(max_width=64, max_height=64, sigma=1.0)

@@ -287,3 +287,25 @@ def test_sigma_not_above_one_is_rejected():
     import sift_amd
     with pytest.raises(sift_amd.SiftGpuError):
         sift_amd.SiftGPU(max_width=64, max_height=64, sigma=1.0)
+
+
+@pytest.mark.parametrize("w,h", [(2, 2), (3, 5), (4, 4), (7, 9), (8, 8), (12, 10)])
+def test_tiny_images(oracle, gpu64, w, h):
+    """Images with zero, one or two octaves (the octave count may even be negative): same counters as the oracle,
+    no features, no error."""
+    img = oracle.vnoise5(w, h, 3)
+    dbg = oracle.Debug(img)
+    got = gpu64.extract(img)
+    assert len(got) == len(dbg.features) == 0
+    assert gpu64.last_octaves() == max(dbg.octaves, 0)
+    assert gpu64.read_counters() == dbg.counters
+
+
+def test_one_pixel_dimension_is_rejected(oracle, gpu64):
+    """UpSample copies column 2C-3 and row 2R-3 (sift.cpp:163-173): with a 1-pixel dimension the reference reads
+    out of bounds there, so such an image is an invalid argument here."""
+    import sift_amd
+    with pytest.raises(sift_amd.SiftGpuError):
+        gpu64.extract(oracle.vnoise5(1, 1, 3))
+    with pytest.raises(sift_amd.SiftGpuError):
+        gpu64.extract(oracle.vnoise5(40, 1, 3))

@@ -393,9 +393,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                     const int cnt = (int)(sp >> 8);
                     if (count + cnt > kDescQueue)
                         break;
-                    const unsigned int first = ((unsigned int)row << 8) | (sp & 255u);
-                    for (int c0 = lane; c0 < cnt; c0 += 64)
-                        queue[count + c0] = (unsigned short)(first + (unsigned int)c0);
+                    // a row has at most 2*radius+1 <= 255 columns: four predicated stores (two when every radius < 64)
+                    const unsigned int first = (((unsigned int)row << 8) | (sp & 255u)) + (unsigned int)lane;
+                    unsigned short *qrow = queue + count + lane;
+#pragma unroll
+                    for (int u = 0; u < (BIG ? 4 : 2); u++)
+                        if (lane + 64 * u < cnt)
+                            qrow[64 * u] = (unsigned short)(first + 64u * u);
                     count += cnt;
                     row++;
                 }

@@ -438,7 +438,8 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
     const int n_iter = (ye - ys + 2 * R + KR - 1) / KR;
     const bool strip_full = x0 + TW <= cols; // wave-uniform: every lane's vector lies inside the row
     const int hx = lane < R ? x0 - R + lane : x0 + TW + (lane - R); // halo column of this lane (lanes < 2R)
-    const int hxr = reflect101_once(hx, cols);
+    // lanes >= 2R have no halo column: they re-read their own first pixel (a line the main load brings anyway)
+    const int hxr = lane < 2 * R ? reflect101_once(hx, cols) : min(xb, cols - 1);
     int xe[V]; // element columns for the strip that crosses the right border
 #pragma unroll
     for (int q = 0; q < V; q++)
@@ -514,7 +515,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                 for (int q = 0; q < V; q++)
                     pv[q] = *reinterpret_cast<const volatile T *>(sr + xe[q]); // kept apart from the vector load above
             }
-            halo[k] = sr[hxr]; // lanes >= 2R load a valid (unused) pixel
+            halo[k] = sr[hxr];
         }
     };
 

@@ -36,6 +36,12 @@ __device__ __forceinline__ int reflect101_once(int p, int len)
     return min(max(p, 0), len - 1);
 }
 
+// acc + k*x.  The double pyramid keeps the reference's separate multiply and add (the library is built without
+// contraction, and results are bit-identical to a scalar evaluation); the float pyramid is a tolerance mode and
+// takes the fused form, which halves the arithmetic of the wide filters.
+__device__ __forceinline__ double blur_madd(double acc, double k, double x) { return acc + k * x; }
+__device__ __forceinline__ float blur_madd(float acc, float k, float x) { return __builtin_fmaf(k, x, acc); }
+
 template <typename T, int V>
 struct VecOf;
 template <>
@@ -100,7 +106,7 @@ __global__ __launch_bounds__(256) void blur_row_k(const T *__restrict__ src, T *
             acc[v] = taps.k[0] * w[v];
 #pragma unroll
             for (int t = 1; t <= 2 * R; t++)
-                acc[v] += taps.k[t] * w[v + t];
+                acc[v] = blur_madd(acc[v], taps.k[t], w[v + t]);
         }
         if (xb + V <= cols) {
             vec_t o;
@@ -178,7 +184,7 @@ __global__ __launch_bounds__(256) void blur_col_k(const T *__restrict__ src, T *
             T acc = taps.k[R] * win[r + R][c];
 #pragma unroll
             for (int t = 1; t <= R; t++)
-                acc += taps.k[R + t] * (win[r + R + t][c] + win[r + R - t][c]);
+                acc = blur_madd(acc, taps.k[R + t], win[r + R + t][c] + win[r + R - t][c]);
             po[c] = acc;
         }
         T *dr = d + (size_t)y * dpitch;
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(256) void blur_fused_k(const T *__restrict__ src, T
                             if (tt == 0)
                                 po[vo] = taps.k[0] * pv[j];
                             else if (tt > 0 && tt <= 2 * R)
-                                po[vo] += taps.k[tt] * pv[j];
+                                po[vo] = blur_madd(po[vo], taps.k[tt], pv[j]);
                         }
                     }
                     (void)prev;
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256) void blur_fused_k(const T *__restrict__ src, T
                     T *pa = reinterpret_cast<T *>(&acc[j]);
 #pragma unroll
                     for (int e = 0; e < V; e++)
-                        pa[e] += taps.k[R + tt] * (pu[e] + pd[e]);
+                        pa[e] = blur_madd(pa[e], taps.k[R + tt], pu[e] + pd[e]);
                 }
                 if (tt < R) {
                     // slide: up[j] <- ring[R + j + tt + 1], dn[j] <- ring[R + j - tt - 1]
@@ -585,7 +591,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                         if (tt == 0)
                             po[vo] = taps.k[0] * pv[j];
                         else if (tt > 0 && tt <= 2 * R)
-                            po[vo] += taps.k[tt] * pv[j];
+                            po[vo] = blur_madd(po[vo], taps.k[tt], pv[j]);
                     }
                 }
             }
@@ -609,7 +615,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                     const T *pd = reinterpret_cast<const T *>(&win[R + k - tt]);
 #pragma unroll
                     for (int e = 0; e < V; e++)
-                        pa[e] += taps.k[R + tt] * (pu[e] + pd[e]);
+                        pa[e] = blur_madd(pa[e], taps.k[R + tt], pu[e] + pd[e]);
                 }
                 const int y = ys + n0 + k;
                 if (y < ye) {
@@ -658,7 +664,7 @@ __global__ __launch_bounds__(256) void blur_row_any_k(const T *src, T *dst, int 
     int h = n / 2;
     T acc = taps[0] * s[reflect101(x - h, cols)];
     for (int t = 1; t < n; t++)
-        acc += taps[t] * s[reflect101(x - h + t, cols)];
+        acc = blur_madd(acc, taps[t], s[reflect101(x - h + t, cols)]);
     dst[blockIdx.z * dimg + (size_t)y * dpitch + x] = acc;
 }
 
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(256) void blur_col_any_k(const T *src, T *dst, int 
     int h = n / 2;
     T acc = taps[h] * s[(size_t)y * spitch];
     for (int t = 1; t <= h; t++)
-        acc += taps[h + t] * (s[(size_t)reflect101(y + t, rows) * spitch] + s[(size_t)reflect101(y - t, rows) * spitch]);
+        acc = blur_madd(acc, taps[h + t], s[(size_t)reflect101(y + t, rows) * spitch] + s[(size_t)reflect101(y - t, rows) * spitch]);
     dst[blockIdx.z * dimg + (size_t)y * dpitch + x] = acc;
 }
 

@@ -415,6 +415,10 @@ static size_t fused_lds_bytes()
 // resident waves per SIMD the register allocation of each radius aims at
 constexpr int win_waves_per_simd(int R) { return R <= 6 ? SG_WIN_WPE6 : (R <= 8 ? SG_WIN_WPE8 : (R <= 10 ? SG_WIN_WPE10 : SG_WIN_WPE13)); }
 
+// Input rows per iteration: more rows per iteration mean fewer window moves per row (2R per iteration) and fewer LDS
+// hand-offs; worth its registers only at the widest radius, whose kernel runs at two waves per SIMD anyway.
+constexpr int win_rows_per_iter(int R) { return R > 10 ? 4 : 2; }
+
 template <typename T, int R, int V, bool UPS = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(win_waves_per_simd(R), win_waves_per_simd(R))))
 void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols, int spitch, int dpitch, size_t simg,
@@ -423,11 +427,11 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
 {
     typedef typename VecOf<T, V>::type vec_t;
     constexpr int TW = 64 * V;
-    constexpr int KR = 2;                              // input rows per iteration
+    constexpr int KR = win_rows_per_iter(R);           // input rows per iteration
     constexpr int WIN = 2 * R + KR;                    // rows in the register window
     constexpr int NWIN = (V + 2 * R + V - 1) / V;      // vectors per row window
     constexpr int RAWW = (R + TW + NWIN * V + 3) & ~3; // raw row image incl. read overshoot, 16-byte rows
-    static_assert((2 * R) % KR == 0, "the first complete window must end on an iteration boundary");
+    static_assert(KR % 2 == 0, "row parity inside an iteration is the image's");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     T *raw = reinterpret_cast<T *>(smem_raw) + (size_t)wave * KR * RAWW;
@@ -453,7 +457,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
 
     // Input rows are fetched PF iterations ahead of their use: the arithmetic of one iteration is shorter than the
     // memory latency under load, and a wave has few neighbours on its SIMD to hide it.
-    constexpr int PF = UPS ? 1 : SG_WIN_PF;
+    constexpr int PF = (UPS || KR > 2) ? 1 : SG_WIN_PF;
     vec_t mainv_s[PF][KR];
     T halo_s[PF][KR];
     // UPS: the input plane is the 2x upsampling (reference UpSample, sift/sift.cpp:111-175) of a double gray plane
@@ -600,9 +604,11 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the raw image is overwritten next
         // ---- column pass: output rows n0 .. n0+KR-1 (segment-relative) from window rows k .. k+2R ----
         const int n0 = KR * t - 2 * R;
-        if (n0 >= 0 && xb < cols) {
+        if (n0 + KR > 0 && xb < cols) {
 #pragma unroll
             for (int k = 0; k < KR; k++) {
+                if (n0 + k < 0)
+                    continue; // the window is not complete for this row yet (2R is not a multiple of KR)
                 vec_t acc;
                 T *pa = reinterpret_cast<T *>(&acc);
                 const T *pc = reinterpret_cast<const T *>(&win[R + k]);
@@ -646,7 +652,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
 template <typename T, int R, int V>
 static size_t win_lds_bytes()
 {
-    constexpr int TW = 64 * V, KR = 2;
+    constexpr int TW = 64 * V, KR = win_rows_per_iter(R);
     constexpr int NWIN = (V + 2 * R + V - 1) / V, RAWW = (R + TW + NWIN * V + 3) & ~3;
     return sizeof(T) * (size_t)4 * KR * RAWW;
 }

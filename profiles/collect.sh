@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collects the round's rocprofv3 evidence for `python bench.py` on the GPU box (run through gpurun from the repo root):
+# Collects the rocprofv3 evidence for `python bench.py` on the GPU box (run through gpurun from the repo root):
 #   1. --kernel-trace --stats   -> per-kernel average durations
 #   2. --pmc FETCH_SIZE         -> L2 fabric read requests   (own pass)
 #   3. --pmc WRITE_SIZE         -> L2 fabric write requests  (own pass)

@@ -5,6 +5,17 @@
 // out in the reference's raster order (octave, layer, y, x), so expanding the set bits in word order
 // reproduces the emission order of the reference's nested loops (sift/sift.cpp:925-938) without a sort.
 #include "sg_internal.h"
+#include <stdlib.h>
+
+#ifndef SG_DET_RS
+#define SG_DET_RS 16
+#endif
+#ifndef SG_DET_D
+#define SG_DET_D 3
+#endif
+#ifndef SG_DET_XCD
+#define SG_DET_XCD 1
+#endif
 
 namespace sg {
 
@@ -46,16 +57,18 @@ __device__ __forceinline__ float wave_shift(float v, float edge)
     return __int_as_float(wave_shift_dword<UP>(__float_as_int(v), __float_as_int(edge)));
 }
 
-// ---- fused DoG + extrema scan ----------------------------------------------------------------------
+// ---- fused DoG + extrema scan, rows loaded into registers ------------------------------------------------
+// The form for planes the staged kernel below does not take (level rows not 16-byte aligned, or a plane of 2 GB or
+// more); SIFTGPU_DETECT_DIRECT=1 in the environment selects it everywhere.
 // One wave owns a 64-pixel segment of RS consecutive rows and all three scanned layers.  Each lane
 // keeps, for the 5 DoG levels, the extremes of a 3-row x 3-column window as running column/row partial
 // maxima and minima and slides them down the rows.
 // isExtremum (reference sift/sift.cpp:473-526): val > 0 -> no neighbour (27 incl. centre) greater;
 // otherwise no neighbour smaller.  Pre-threshold |val| > thresh is strict (sift.cpp:945).
 template <typename T, bool FROM_DOG, bool NOINT, int RS>
-__global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned long long *words, size_t words_img,
-                                                unsigned int *chunk_sums, size_t chunks_img,
-                                                unsigned long long *counters, double thresh)
+__global__ __launch_bounds__(256) void detect_direct_k(OctaveTab tab, int o, unsigned long long *words,
+                                                       size_t words_img, unsigned int *chunk_sums, size_t chunks_img,
+                                                       unsigned long long *counters, double thresh)
 {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
@@ -197,18 +210,268 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
         atomicAdd(&counters[(size_t)b * 8 + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
 }
 
+// ---- the same scan with its rows staged through LDS by the memory pipeline (the form normally used) --------
+// detect_direct_k keeps one row of each level in flight per wave and no more: loaded values need registers.  Here every
+// wave owns a ring of D row slots in LDS and fills it with loads that write LDS directly (global_load_lds_dwordx4:
+// no register destination, lane i of the instruction writes 16 bytes at the slot's base + 16 i), D - 1 rows ahead of
+// the row it is working on, so that the bytes a compute unit has in flight no longer depend on its register file.
+// A row slot holds, per level, the 66 columns x0-1 .. x0+64 of the wave's 64-pixel segment (x0 - 1 = 4 + 64 k is a
+// multiple of four, so every 16-byte piece is aligned); a lane reads its three columns from there.
+// Ordering: a wave reads a slot only after its own s_waitcnt vmcnt(n) has retired the loads that fill it (loads
+// retire in order; stores in between only make the count conservative), and refills a slot only after the
+// s_waitcnt lgkmcnt(0) that returned its reads.  No other wave touches the ring.
+template <int N>
+__device__ __forceinline__ void wait_vm()
+{
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// waits until at most min(ahead, A) * NL of the wave's loads are outstanding
+template <int NL, int A>
+__device__ __forceinline__ void wait_rows_ahead(int ahead)
+{
+    if constexpr (A == 0) {
+        wait_vm<0>();
+    } else {
+        if (ahead >= A)
+            wait_vm<A * NL>();
+        else
+            wait_rows_ahead<NL, A - 1>(ahead);
+    }
+}
+// 16 bytes per active lane from base + voff to LDS at lds_dst + 16 * lane (lds_dst wave-uniform)
+__device__ __forceinline__ void load16_to_lds(unsigned int lds_dst, unsigned long long base, unsigned int voff)
+{
+    unsigned int keep;
+    asm volatile("s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_dst), "v"(voff), "s"(base)
+                 : "memory");
+}
+
+template <typename T, bool FROM_DOG, int D>
+struct DetectRing {
+    static constexpr int NL = FROM_DOG ? kDogLevels : kLevels; // planes read per row
+    static constexpr int EPC = 16 / (int)sizeof(T);            // elements per 16-byte piece
+    static constexpr int NCH = (66 + EPC - 1) / EPC;           // pieces per level and row
+    static constexpr int LSTRIDE = NCH * 16;
+    static constexpr int ROWSLOT = NL * LSTRIDE;
+    static constexpr int WAVE_BYTES = D * ROWSLOT;
+};
+
+template <typename T, bool FROM_DOG, bool NOINT, int RS, int D>
+__global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned long long *words, size_t words_img,
+                                                unsigned int *chunk_sums, size_t chunks_img,
+                                                unsigned long long *counters, double thresh, unsigned int n_img)
+{
+    using R = DetectRing<T, FROM_DOG, D>;
+    constexpr int NL = R::NL;
+    __shared__ __align__(16) unsigned char ring[4 * R::WAVE_BYTES];
+    __shared__ unsigned int blk_ctr[3];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
+    const int nrows = tab.nrows[o], wpr = tab.wpr[o];
+    // Workgroups are handed to the eight XCDs in turn, and each XCD has its own L2.  The launch is one-dimensional
+    // and workgroup i works on tile (i % 8) * (n / 8) + i / 8, so that an XCD walks a contiguous run of tiles: the
+    // rows two vertically adjacent tiles share are then read by the same XCD, not long apart.
+    const unsigned int gx = (wpr + 3) / 4, gy = (nrows + RS - 1) / RS;
+    const unsigned int per_xcd = gridDim.x >> 3;
+    const unsigned int tile = SG_DET_XCD ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= gx * gy * n_img)
+        return;
+    const int b = tile / (gx * gy);
+    const unsigned int in_img = tile - b * (gx * gy);
+    const int by = in_img / gx, bx = in_img - by * gx;
+    const int k = bx * 4 + wave;
+    const int x = kBorder + 64 * k + lane;
+    const bool x_ok = x < cols - kBorder;
+    const int y_begin = kBorder + by * RS;
+    const int y_end = k < wpr ? min(y_begin + RS, rows - kBorder) : y_begin;
+    if (threadIdx.x < 3)
+        blk_ctr[threadIdx.x] = 0;
+    __syncthreads();
+    unsigned long long *wbase = words + (size_t)b * words_img + tab.wbase[o];
+    unsigned int *csum = chunk_sums + (size_t)b * chunks_img;
+
+    unsigned int n00 = 0, n0 = 0, n1 = 0;
+    if (y_begin < y_end) {
+        const int n_stage = y_end - y_begin + 2; // rows y_begin-1 .. y_end
+        unsigned long long base[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+            base[l] = (unsigned long long)tab.lv[o][l] + ((unsigned long long)b * tab.img_stride[o]) * sizeof(T);
+        // A piece that would run past the row end starts at the last whole piece instead: it then holds no column the
+        // scan needs (those end at cols - kBorder), and the read stays inside the row.
+        const int c0 = min(kBorder - 1 + 64 * k + R::EPC * lane, cols - R::EPC);
+        unsigned int voff = ((unsigned int)(y_begin - 1) * (unsigned int)pitch + (unsigned int)c0) * (unsigned int)sizeof(T);
+        const unsigned int vstep = (unsigned int)pitch * (unsigned int)sizeof(T);
+        const unsigned int lds_wave = (unsigned int)(uintptr_t)ring + (unsigned int)wave * R::WAVE_BYTES;
+        const unsigned char *ring_wave = ring + wave * R::WAVE_BYTES;
+        auto stage_row = [&](int slot) { // next row of all levels into the slot
+            if (lane < R::NCH) {
+#pragma unroll
+                for (int l = 0; l < NL; l++)
+                    load16_to_lds(lds_wave + slot * R::ROWSLOT + l * R::LSTRIDE, base[l], voff);
+            }
+            voff += vstep;
+        };
+
+        T rmx01[kDogLevels], rmn01[kDogLevels], rmx1[kDogLevels], rmn1[kDogLevels], rmx2[kDogLevels], rmn2[kDogLevels];
+        T cen1[3], cen2[3];
+        int staged = 0, taken = 0, slot = 0;
+        // takes the next staged row: fills rmx2 / rmn2 / cen2 from it, then restages its slot
+        auto take_row = [&]() {
+            wait_rows_ahead<NL, D - 1>(staged - taken - 1);
+            const T *p = reinterpret_cast<const T *>(ring_wave + slot * R::ROWSLOT) + lane;
+            T g[NL][3];
+#pragma unroll
+            for (int l = 0; l < NL; l++) {
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    g[l][q] = p[l * (R::LSTRIDE / (int)sizeof(T)) + q];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot's reads have returned: it may be refilled
+            taken++;
+            if (staged < n_stage) {
+                stage_row(slot);
+                staged++;
+            }
+            slot = slot + 1 == D ? 0 : slot + 1;
+#pragma unroll
+            for (int l = 0; l < kDogLevels; l++) {
+                T d[3];
+#pragma unroll
+                for (int q = 0; q < 3; q++)
+                    d[q] = FROM_DOG ? g[l][q] : g[l + 1 < NL ? l + 1 : l][q] - g[l][q];
+                rmx2[l] = vmax(vmax(d[0], d[1]), d[2]);
+                rmn2[l] = vmin(vmin(d[0], d[1]), d[2]);
+                if (l >= 1 && l <= 3)
+                    cen2[l - 1] = d[1];
+            }
+        };
+        {
+            int fill_slot = 0;
+            for (; staged < min(D, n_stage); staged++)
+                stage_row(fill_slot++);
+        }
+        take_row(); // row y_begin - 1
+#pragma unroll
+        for (int l = 0; l < kDogLevels; l++) {
+            rmx1[l] = rmx2[l];
+            rmn1[l] = rmn2[l];
+        }
+        take_row(); // row y_begin
+#pragma unroll
+        for (int l = 0; l < kDogLevels; l++) {
+            rmx01[l] = vmax(rmx1[l], rmx2[l]);
+            rmn01[l] = vmin(rmn1[l], rmn2[l]);
+            rmx1[l] = rmx2[l];
+            rmn1[l] = rmn2[l];
+        }
+#pragma unroll
+        for (int l = 0; l < 3; l++)
+            cen1[l] = cen2[l];
+        for (int y = y_begin; y < y_end; y++) {
+            take_row(); // row y + 1
+            T mx[kDogLevels], mn[kDogLevels];
+#pragma unroll
+            for (int l = 0; l < kDogLevels; l++) {
+                mx[l] = vmax(rmx01[l], rmx2[l]);
+                mn[l] = vmin(rmn01[l], rmn2[l]);
+            }
+            n00 += __popcll(__ballot(x_ok));
+#pragma unroll
+            for (int layer = 1; layer <= 3; layer++) {
+                T val = cen1[layer - 1];
+                bool pre = x_ok && (fabs((double)val) > thresh);
+                T hi = mx[layer], lo = mn[layer];
+                if (!NOINT) {
+                    hi = vmax(vmax(hi, mx[layer - 1]), mx[layer + 1]);
+                    lo = vmin(vmin(lo, mn[layer - 1]), mn[layer + 1]);
+                }
+                bool ext = pre && (val > (T)0 ? !(val < hi) : !(val > lo));
+                unsigned long long mpre = __ballot(pre);
+                unsigned long long mext = __ballot(ext);
+                n0 += __popcll(mpre);
+                n1 += __popcll(mext);
+                if (lane == 0) {
+                    unsigned int widx = ((unsigned int)(layer - 1) * nrows + (y - kBorder)) * wpr + k;
+                    wbase[widx] = mext;
+                    if (mext)
+                        atomicAdd(&csum[(tab.wbase[o] + widx) / kChunkWords], (unsigned int)__popcll(mext));
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < kDogLevels; l++) {
+                rmx01[l] = vmax(rmx1[l], rmx2[l]);
+                rmn01[l] = vmin(rmn1[l], rmn2[l]);
+                rmx1[l] = rmx2[l];
+                rmn1[l] = rmn2[l];
+            }
+#pragma unroll
+            for (int l = 0; l < 3; l++)
+                cen1[l] = cen2[l];
+        }
+    }
+    if (lane == 0 && n00) {
+        atomicAdd(&blk_ctr[0], n00 * 3u);
+        atomicAdd(&blk_ctr[1], n0);
+        atomicAdd(&blk_ctr[2], n1);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3 && blk_ctr[threadIdx.x])
+        atomicAdd(&counters[(size_t)b * 8 + threadIdx.x], (unsigned long long)blk_ctr[threadIdx.x]);
+}
+
+// true when the staged scan applies: 16-byte aligned level rows and row offsets that fit 32 bits
+static bool detect_staged_ok(const OctaveTab &tab, int o, int prec)
+{
+    const size_t esz = prec == SG_F64 ? 8 : 4;
+    const int nl = tab.from_dog ? kDogLevels : kLevels;
+    if (getenv("SIFTGPU_DETECT_DIRECT"))
+        return false;
+    if ((size_t)tab.pitch[o] * esz % 16 || (size_t)tab.img_stride[o] * esz % 16)
+        return false;
+    if ((size_t)tab.rows[o] * tab.pitch[o] * esz >= (1ull << 31) || tab.cols[o] < 16)
+        return false;
+    for (int l = 0; l < nl; l++)
+        if ((uintptr_t)tab.lv[o][l] % 16)
+            return false;
+    return true;
+}
+
 void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words, size_t words_img_stride,
                    unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
                    double thresh, int nointerval, int prec, hipStream_t s)
 {
     if (tab.nrows[o] <= 0 || tab.wpr[o] <= 0)
         return;
+    bool fd = tab.from_dog != 0, ni = nointerval != 0;
+    if (detect_staged_ok(tab, o, prec)) {
+        constexpr int RS = SG_DET_RS, D = SG_DET_D;
+        const unsigned int tiles = (unsigned int)((tab.wpr[o] + 3) / 4) * ((tab.nrows[o] + RS - 1) / RS) * B;
+        const unsigned int g = (tiles + 7) / 8 * 8;
+#define SG_DET(T, FD, NI)                                                                                              \
+    detect_k<T, FD, NI, RS, D><<<g, 256, 0, s>>>(tab, o, words, words_img_stride, chunk_sums, chunks_img_stride, \
+                                                      counters, thresh, (unsigned int)B)
+        if (prec == SG_F64) {
+            if (fd) { if (ni) SG_DET(double, true, true); else SG_DET(double, true, false); }
+            else { if (ni) SG_DET(double, false, true); else SG_DET(double, false, false); }
+        } else {
+            if (fd) { if (ni) SG_DET(float, true, true); else SG_DET(float, true, false); }
+            else { if (ni) SG_DET(float, false, true); else SG_DET(float, false, false); }
+        }
+#undef SG_DET
+        return;
+    }
     constexpr int RS = 16;
     dim3 g((tab.wpr[o] + 3) / 4, (tab.nrows[o] + RS - 1) / RS, B);
 #define SG_DET(T, FD, NI)                                                                                      \
-    detect_k<T, FD, NI, RS><<<g, 256, 0, s>>>(tab, o, words, words_img_stride, chunk_sums, chunks_img_stride, \
+    detect_direct_k<T, FD, NI, RS><<<g, 256, 0, s>>>(tab, o, words, words_img_stride, chunk_sums, chunks_img_stride, \
                                               counters, thresh)
-    bool fd = tab.from_dog != 0, ni = nointerval != 0;
     if (prec == SG_F64) {
         if (fd) { if (ni) SG_DET(double, true, true); else SG_DET(double, true, false); }
         else { if (ni) SG_DET(double, false, true); else SG_DET(double, false, false); }

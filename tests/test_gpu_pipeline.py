@@ -115,6 +115,40 @@ def test_nointerval_variant(oracle):
     assert np.array_equal(got["x"], ref["x"]) and np.array_equal(got["y"], ref["y"])
 
 
+@pytest.mark.parametrize("w,h,seed", [(640, 480, 3), (131, 77, 3), (23, 310, 9)])
+def test_extrema_scan_forms_agree(oracle, gpu64, gpu32, w, h, seed, monkeypatch):
+    """The extrema scan has two forms: rows staged through LDS (the one normally launched) and rows loaded into
+    registers (for planes the staged form does not take; SIFTGPU_DETECT_DIRECT=1 selects it everywhere).  Both give
+    the oracle's counters and features in double, and identical features to each other in float and without the
+    neighbouring-layer comparison."""
+    import sift_amd
+    img = oracle.vnoise5(w, h, seed)
+    ref, _, ctr, _ = oracle.sift(img)
+    results = []
+    for direct in (False, True):
+        if direct:
+            monkeypatch.setenv("SIFTGPU_DETECT_DIRECT", "1")
+        else:
+            monkeypatch.delenv("SIFTGPU_DETECT_DIRECT", raising=False)
+        got = gpu64.extract(img)
+        assert gpu64.read_counters() == ctr, direct
+        assert len(got) == len(ref)
+        for f in FIELDS_EXACT:
+            assert np.array_equal(got[f], ref[f]), (f, direct)
+        assert np.array_equal(got["descriptor"], ref["descriptor"])
+        f32 = gpu32.extract(img)
+        c32 = gpu32.read_counters()
+        with sift_amd.SiftGPU(max_width=w, max_height=h, nointerval=True) as ctx:
+            ni = ctx.extract(img)
+            cni = ctx.read_counters()
+        results.append((f32, c32, ni, cni))
+    (a32, ac32, ani, acni), (b32, bc32, bni, bcni) = results
+    assert ac32 == bc32 and acni == bcni
+    for f in a32.dtype.names:
+        assert a32[f].tobytes() == b32[f].tobytes(), f
+        assert ani[f].tobytes() == bni[f].tobytes(), f
+
+
 @pytest.mark.parametrize("sigma", [3.2, 8.0])
 def test_wide_windows_through_stage_entry_points(oracle, gpu64, sigma):
     """Keypoints whose orientation / descriptor windows outgrow the common kernels' tables (orientation

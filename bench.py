@@ -77,7 +77,7 @@ def measured_traffic(kernel, tname, batch, width, height):
             if d and name.startswith("sg::detect_k<%s," % d.group(1)):
                 return rec["hbm_bytes_per_launch"]
             if m and name.startswith("sg::%s<%s, %s," % (m.group(1), m.group(2), m.group(3))):
-                if m.group(1) != "blur_win_k" or name.endswith("true>") == bool(m.group(4)):
+                if m.group(1) != "blur_win_k" or name.endswith("true>") == bool(m.group(4)):  # true> = upsampling form
                     return rec["hbm_bytes_per_launch"]
     return None
 
@@ -251,10 +251,13 @@ def main():
     blur_mode = os.environ.get("SIFTGPU_BLUR", "")
     fused = blur_mode != "2pass"
 
-    def fused_name(radius):
-        """The fused kernel the library launches (kernels_blur.hip: the register-window variant; the LDS-ring
-        variant with SIFTGPU_BLUR=ring)."""
-        return "blur_fused_k" if blur_mode == "ring" else "blur_win_k"
+    def fused_name(ups):
+        """The fused kernel the library launches (kernels_blur.hip): input rows staged by direct-to-LDS loads
+        (blur_dma_k); the base blur, which forms its input by upsampling, and SIFTGPU_BLUR_DIRECT=1 take the
+        register-staged form (blur_win_k); SIFTGPU_BLUR=ring the LDS-ring variant."""
+        if blur_mode == "ring":
+            return "blur_fused_k"
+        return "blur_win_k" if ups or os.environ.get("SIFTGPU_BLUR_DIRECT") else "blur_dma_k"
 
     dims = octave_dims(W, H)
     # Algorithmic bytes of one blur launch: every pixel of the level read once and written once
@@ -275,7 +278,7 @@ def main():
             if ups:  # the base blur reads the double gray plane at input resolution instead of an upsampled plane
                 nbytes = (esize * float(dims[0][0] * dims[0][1]) + 8.0 * W * H) * B * K
             if ms > 0:
-                kname = ("%s<%s,R=%d%s>" % (fused_name(radius_name[lvl]), tname, radius_name[lvl],
+                kname = ("%s<%s,R=%d%s>" % (fused_name(ups), tname, radius_name[lvl],
                                              ",upsampling" if ups else "")) if fused else \
                     ("blur_%s_k<%s,R=%d>" % (kind, tname, radius_name[lvl]))
                 blur[key] = {"kernel": kname, "taps": taps[lvl], "launches": int(ln), "avg_us": 1e3 * ms / max(ln, 1),

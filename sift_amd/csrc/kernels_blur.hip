@@ -10,6 +10,7 @@
 //
 // Both passes are HBM-bound streaming kernels: 16-byte accesses per lane, halos staged in LDS.
 #include "sg_internal.h"
+#include "sg_lds_dma.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -657,6 +658,241 @@ static size_t win_lds_bytes()
     return sizeof(T) * (size_t)4 * KR * RAWW;
 }
 
+// ---- the register-window kernel with its input rows staged by direct-to-LDS loads ---------------------------
+// Same strips, same window, same arithmetic as blur_win_k; what differs is how an input row reaches the wave's raw
+// row image.  There the lanes load the row into registers (one or two iterations ahead) and store it to LDS; here
+// the wave owns a ring of DI iteration slots (KR rows each) in LDS and fills it with global_load_lds_dwordx4, DI - 1
+// iterations ahead of the one it works on: no registers hold data in flight, no LDS stores are issued, and the
+// distance to the loads no longer depends on the register budget.
+// A row image starts A columns left of the halo, A = (V - R mod V) mod V, so that its first column (x0 - R - A) is
+// a multiple of V and every 16-byte piece is aligned in memory; the lane windows start at the image's element
+// lane*V (aligned 16-byte LDS reads) and tap t of output v is window element A + v + t.  Pieces that would start
+// outside [0, pitch - V] are moved inside; they hold no column a stored output needs, except the reflected ones:
+// those (columns -R..-1 in the first strip, cols..cols+R-1 where the halo crosses the right border) are copied
+// inside LDS from their mirror columns after the row has landed.
+#ifndef SG_DMA_DI
+#define SG_DMA_DI 4
+#endif
+#ifndef SG_DMA_DI13
+#define SG_DMA_DI13 3
+#endif
+#ifndef SG_DMA_SPLIT_ROWS
+#define SG_DMA_SPLIT_ROWS(R) ((R) >= 10)
+#endif
+constexpr int dma_ring_iters(int R) { return R > 10 ? SG_DMA_DI13 : SG_DMA_DI; }
+#ifndef SG_DMA_WPE6
+#define SG_DMA_WPE6 4
+#endif
+#ifndef SG_DMA_WPE8
+#define SG_DMA_WPE8 3
+#endif
+#ifndef SG_DMA_WPE10
+#define SG_DMA_WPE10 3
+#endif
+#ifndef SG_DMA_WPE13
+#define SG_DMA_WPE13 2
+#endif
+// resident waves per SIMD the register allocation of each radius aims at
+constexpr int dma_waves_per_simd(int R) { return R <= 6 ? SG_DMA_WPE6 : (R <= 8 ? SG_DMA_WPE8 : (R <= 10 ? SG_DMA_WPE10 : SG_DMA_WPE13)); }
+
+template <typename T, int R, int V>
+struct WinDma {
+    static constexpr int TW = 64 * V;
+    static constexpr int KR = win_rows_per_iter(R);
+    static constexpr int A = (V - R % V) % V;
+    static constexpr int NWIN = (A + 2 * R + V + V - 1) / V; // 16-byte vectors per lane window
+    static constexpr int NP = 64 + NWIN - 1;                 // 16-byte pieces per row image
+    static constexpr int ROWB = NP * 16;
+    static constexpr int DI = dma_ring_iters(R);
+    static constexpr int WAVE_BYTES = DI * KR * ROWB;
+    static_assert(NP > 64 && NP <= 128, "two load instructions per row");
+    static_assert((DI - 1) * 2 * KR < 64, "outstanding loads fit the counter");
+};
+
+template <typename T, int R, int V>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd(R), dma_waves_per_simd(R))))
+void blur_dma_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols, int spitch, int dpitch, size_t simg,
+                size_t dimg, int seg, Taps<T> taps, T *__restrict__ dec, int dec_rows, int dec_cols, int dec_pitch,
+                size_t dec_img)
+{
+    typedef typename VecOf<T, V>::type vec_t;
+    using G = WinDma<T, R, V>;
+    constexpr int TW = G::TW, KR = G::KR, WIN = 2 * R + KR, A = G::A, NWIN = G::NWIN, DI = G::DI;
+    constexpr int ROWE = G::ROWB / (int)sizeof(T); // elements per row image
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int x0 = (blockIdx.x * 4 + wave) * TW;
+    const int ys = blockIdx.y * seg;
+    if (x0 >= cols)
+        return; // the whole wave, before it has requested anything; there is no barrier in this kernel
+    const int ye = min(ys + seg, rows);
+    const int xb = x0 + lane * V;
+    const T *s = src + blockIdx.z * simg;
+    T *d = dst + blockIdx.z * dimg;
+    const int n_iter = (ye - ys + 2 * R + KR - 1) / KR;
+    const bool strip_full = x0 + TW <= cols; // wave-uniform: every lane's vector lies inside the row
+    const int cbase = x0 - R - A;            // column of element 0 of a row image
+    T *ring = reinterpret_cast<T *>(smem_raw + (size_t)wave * G::WAVE_BYTES);
+    const unsigned int lds_wave = (unsigned int)(uintptr_t)smem_raw + (unsigned int)wave * G::WAVE_BYTES;
+    const unsigned int voff0 = (unsigned int)min(max(cbase + V * lane, 0), spitch - V) * (unsigned int)sizeof(T);
+    const unsigned int voff1 = (unsigned int)min(max(cbase + TW + V * lane, 0), spitch - V) * (unsigned int)sizeof(T);
+    const bool left_edge = x0 == 0, right_edge = x0 + TW + R > cols; // wave-uniform
+    auto stage = [&](int t, int slot) { // the KR rows of iteration t into a slot
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const int yy = reflect101_once(ys - R + KR * t + k, rows);
+            const unsigned long long base = (unsigned long long)(uintptr_t)(s + (size_t)yy * spitch);
+            const unsigned int to = lds_wave + (unsigned int)((slot * KR + k) * G::ROWB);
+            load16_to_lds(to, base, voff0);
+            if (lane < G::NP - 64)
+                load16_to_lds(to + 1024u, base, voff1);
+        }
+    };
+
+    vec_t win[WIN];
+#pragma unroll
+    for (int j = 0; j < WIN; j++) {
+        T *pw = reinterpret_cast<T *>(&win[j]);
+#pragma unroll
+        for (int e = 0; e < V; e++)
+            pw[e] = (T)0;
+    }
+    for (int t = 0; t < min(DI, n_iter); t++)
+        stage(t, t);
+    int slot = 0;
+    for (int t = 0; t < n_iter; t++) {
+        // iterations t+1 .. t+DI-1 (those that exist) may stay in flight
+        wait_groups_ahead<2 * KR, DI - 1>(n_iter - 1 - t);
+        T *raw = ring + slot * (KR * ROWE);
+        if (left_edge) {
+#pragma unroll
+            for (int k = 0; k < KR; k++)
+                if (lane < R) {
+                    const T v = raw[k * ROWE + R + A + 1 + lane]; // column 1 + lane
+                    raw[k * ROWE + R + A - 1 - lane] = v;         // is column -1 - lane
+                }
+        }
+        if (right_edge) {
+            const int to = cols + lane - cbase, from = cols - 2 - lane - cbase;
+#pragma unroll
+            for (int k = 0; k < KR; k++)
+                if (lane < R && to < ROWE) {
+                    const T v = raw[k * ROWE + from];
+                    raw[k * ROWE + to] = v;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j + KR < WIN; j++)
+            win[j] = win[j + KR];
+        // ---- row pass ----
+        // The row windows are read in pieces of CH vectors, one piece ahead of the arithmetic: the reads of a piece
+        // are issued, then the piece before it is used.  Two pieces are live at a time, which bounds the registers
+        // (the wide radii split a row's window into two pieces; the others take a row per piece).
+        {
+            constexpr int NPC = SG_DMA_SPLIT_ROWS(R) ? 2 : 1; // pieces per row
+            constexpr int CH = (NWIN + NPC - 1) / NPC;
+            vec_t rv[2][CH];
+            vec_t o[KR];
+            auto read_piece = [&](int step, vec_t *buf) {
+                const int k = step / NPC, c = step % NPC;
+#pragma unroll
+                for (int q = c * CH; q < (c + 1) * CH && q < NWIN; q++)
+                    buf[q - c * CH] = *reinterpret_cast<const vec_t *>(raw + k * ROWE + lane * V + q * V);
+            };
+            read_piece(0, rv[0]);
+#pragma unroll
+            for (int step = 0; step < KR * NPC; step++) {
+                const int k = step / NPC, c = step % NPC;
+                if (step + 1 < KR * NPC)
+                    read_piece(step + 1, rv[(step + 1) & 1]);
+                asm volatile("" ::: "memory");
+                T *po = reinterpret_cast<T *>(&o[k]);
+#pragma unroll
+                for (int q = c * CH; q < (c + 1) * CH && q < NWIN; q++) {
+                    const vec_t v = rv[step & 1][q - c * CH];
+                    const T *pv = reinterpret_cast<const T *>(&v);
+                    // window element index e = q*V + j feeds output vo with tap tt = e - vo - A
+#pragma unroll
+                    for (int j = 0; j < V; j++) {
+                        const int e = q * V + j;
+#pragma unroll
+                        for (int vo = 0; vo < V; vo++) {
+                            const int tt = e - vo - A;
+                            if (tt == 0)
+                                po[vo] = taps.k[0] * pv[j];
+                            else if (tt > 0 && tt <= 2 * R)
+                                po[vo] = blur_madd(po[vo], taps.k[tt], pv[j]);
+                        }
+                    }
+                }
+                // the piece after next is read after this piece's arithmetic
+#pragma unroll
+                for (int vo = 0; vo < V; vo++)
+                    asm volatile("" : "+v"(po[vo])::"memory");
+                if (c == NPC - 1)
+                    win[2 * R + k] = o[k];
+            }
+        }
+        wait_lgkm0(); // the slot's reads have returned: it is loaded again
+        if (t + DI < n_iter)
+            stage(t + DI, slot);
+        slot = slot + 1 == DI ? 0 : slot + 1;
+        // ---- column pass: output rows n0 .. n0+KR-1 (segment-relative) from window rows k .. k+2R ----
+        const int n0 = KR * t - 2 * R;
+        if (n0 + KR > 0 && xb < cols) {
+#pragma unroll
+            for (int k = 0; k < KR; k++) {
+                if (n0 + k < 0)
+                    continue;
+                vec_t acc;
+                T *pa = reinterpret_cast<T *>(&acc);
+                const T *pc = reinterpret_cast<const T *>(&win[R + k]);
+#pragma unroll
+                for (int e = 0; e < V; e++)
+                    pa[e] = taps.k[R] * pc[e];
+#pragma unroll
+                for (int tt = 1; tt <= R; tt++) {
+                    const T *pu = reinterpret_cast<const T *>(&win[R + k + tt]);
+                    const T *pd = reinterpret_cast<const T *>(&win[R + k - tt]);
+#pragma unroll
+                    for (int e = 0; e < V; e++)
+                        pa[e] = blur_madd(pa[e], taps.k[R + tt], pu[e] + pd[e]);
+                }
+                const int y = ys + n0 + k;
+                if (y < ye) {
+                    T *dr = d + (size_t)y * dpitch;
+                    if (strip_full) {
+                        *reinterpret_cast<vec_t *>(dr + xb) = acc;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < V; e++)
+                            if (xb + e < cols)
+                                dr[xb + e] = pa[e];
+                    }
+                    // DownSample (reference sift/sift.cpp:59-103) of the level just written: dec(m, n) = dst(2m, 2n)
+                    if ((k & 1) == 0 && dec != nullptr && (y >> 1) < dec_rows) {
+                        T *dd = dec + blockIdx.z * dec_img + (size_t)(y >> 1) * dec_pitch;
+#pragma unroll
+                        for (int e = 0; e < V; e += 2)
+                            if (((xb + e) >> 1) < dec_cols)
+                                dd[(xb + e) >> 1] = pa[e];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// true when blur_dma_k applies: 16-byte aligned rows (SIFTGPU_BLUR_DIRECT=1 keeps the register form everywhere)
+template <typename T, int V>
+static bool blur_dma_ok(const Plane &src)
+{
+    if (getenv("SIFTGPU_BLUR_DIRECT"))
+        return false;
+    return (uintptr_t)src.p % 16 == 0 && src.pitch % V == 0 && src.pitch >= V &&
+           (src.img_stride * sizeof(T)) % 16 == 0 && (size_t)src.pitch * sizeof(T) < (1ull << 31);
+}
+
 // ---- any-radius fallback (one thread per output pixel, taps in global memory) ------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void blur_row_any_k(const T *src, T *dst, int rows, int cols, int spitch,
@@ -838,7 +1074,7 @@ bool blur_fused_supported(const Plane &src, int n)
 // segments per strip as give about two waves per slot (measured best: one wave per slot leaves the chip idle while
 // the slowest waves finish, many more re-read too many halo rows); never so short that the 2R halo rows (re-read
 // and row-filtered again) dominate.  per_row = strips x frames.
-static int win_segment_rows(int rows, long long per_row, int R)
+static int win_segment_rows(int rows, long long per_row, int R, int waves_per_simd)
 {
     static const int n_cu = [] {
         int dev = 0, cu = 0;
@@ -847,7 +1083,7 @@ static int win_segment_rows(int rows, long long per_row, int R)
             cu = 256;
         return cu;
     }();
-    const long long slots = (long long)n_cu * 4 * win_waves_per_simd(R) * 2;
+    const long long slots = (long long)n_cu * 4 * waves_per_simd * 2;
     int nseg_want = (int)(slots / per_row);
     if (nseg_want < 1)
         nseg_want = 1;
@@ -914,7 +1150,8 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
 #undef SG_FUSED_CASE
         return true;
     }
-    const int seg = win_segment_rows(rows, per_row, R);
+    const bool dma = blur_dma_ok<T, V>(src);
+    const int seg = win_segment_rows(rows, per_row, R, dma ? dma_waves_per_simd(R) : win_waves_per_simd(R));
     const int nseg = (rows + seg - 1) / seg;
     T *dec_p = dec ? (T *)dec->p : nullptr;
     const int dec_rows = dec ? dec->rows : 0, dec_cols = dec ? dec->cols : 0, dec_pitch = dec ? dec->pitch : 0;
@@ -922,9 +1159,14 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
     dim3 g((strips + 3) / 4, nseg, B);
 #define SG_WIN_CASE(RR)                                                                                               \
     case RR:                                                                                                          \
-        blur_win_k<T, RR, V><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                                               \
-            (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,      \
-            padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                              \
+        if (dma)                                                                                                      \
+            blur_dma_k<T, RR, V><<<g, 256, 4 * WinDma<T, RR, V>::WAVE_BYTES, s>>>(                                    \
+                (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
+                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                          \
+        else                                                                                                          \
+            blur_win_k<T, RR, V><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                                           \
+                (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
+                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                          \
         break;
     switch (R) {
         SG_WIN_CASE(5)
@@ -952,7 +1194,7 @@ static bool ups_dispatch(const Plane &gray, const Plane &dst, int B, const doubl
     constexpr int TW = 64 * V;
     const int strips = (cols + TW - 1) / TW;
     const long long per_row = (long long)strips * B;
-    const int seg = win_segment_rows(rows, per_row, R);
+    const int seg = win_segment_rows(rows, per_row, R, win_waves_per_simd(R));
     const int nseg = (rows + seg - 1) / seg;
     dim3 g((strips + 3) / 4, nseg, B);
     blur_win_k<T, R, V, true><<<g, 256, win_lds_bytes<T, R, V>(), s>>>(

@@ -5,6 +5,7 @@
 // out in the reference's raster order (octave, layer, y, x), so expanding the set bits in word order
 // reproduces the emission order of the reference's nested loops (sift/sift.cpp:925-938) without a sort.
 #include "sg_internal.h"
+#include "sg_lds_dma.h"
 #include <stdlib.h>
 
 #ifndef SG_DET_RS
@@ -220,38 +221,6 @@ __global__ __launch_bounds__(256) void detect_direct_k(OctaveTab tab, int o, uns
 // Ordering: a wave reads a slot only after its own s_waitcnt vmcnt(n) has retired the loads that fill it (loads
 // retire in order; stores in between only make the count conservative), and refills a slot only after the
 // s_waitcnt lgkmcnt(0) that returned its reads.  No other wave touches the ring.
-template <int N>
-__device__ __forceinline__ void wait_vm()
-{
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-// waits until at most min(ahead, A) * NL of the wave's loads are outstanding
-template <int NL, int A>
-__device__ __forceinline__ void wait_rows_ahead(int ahead)
-{
-    if constexpr (A == 0) {
-        wait_vm<0>();
-    } else {
-        if (ahead >= A)
-            wait_vm<A * NL>();
-        else
-            wait_rows_ahead<NL, A - 1>(ahead);
-    }
-}
-// 16 bytes per active lane from base + voff to LDS at lds_dst + 16 * lane (lds_dst wave-uniform)
-__device__ __forceinline__ void load16_to_lds(unsigned int lds_dst, unsigned long long base, unsigned int voff)
-{
-    unsigned int keep;
-    asm volatile("s_mov_b32 %0, m0\n\t"
-                 "s_mov_b32 m0, %1\n\t"
-                 "s_nop 0\n\t"
-                 "global_load_lds_dwordx4 %2, %3\n\t"
-                 "s_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "s"(lds_dst), "v"(voff), "s"(base)
-                 : "memory");
-}
-
 template <typename T, bool FROM_DOG, int D>
 struct DetectRing {
     static constexpr int NL = FROM_DOG ? kDogLevels : kLevels; // planes read per row
@@ -324,7 +293,7 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
         int staged = 0, taken = 0, slot = 0;
         // takes the next staged row: fills rmx2 / rmn2 / cen2 from it, then restages its slot
         auto take_row = [&]() {
-            wait_rows_ahead<NL, D - 1>(staged - taken - 1);
+            wait_groups_ahead<NL, D - 1>(staged - taken - 1);
             const T *p = reinterpret_cast<const T *>(ring_wave + slot * R::ROWSLOT) + lane;
             T g[NL][3];
 #pragma unroll
@@ -333,7 +302,7 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
                 for (int q = 0; q < 3; q++)
                     g[l][q] = p[l * (R::LSTRIDE / (int)sizeof(T)) + q];
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // the slot's reads have returned: it may be refilled
+            wait_lgkm0(); // the slot's reads have returned: it may be refilled
             taken++;
             if (staged < n_stage) {
                 stage_row(slot);

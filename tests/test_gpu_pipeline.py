@@ -116,22 +116,29 @@ def test_nointerval_variant(oracle):
 
 
 @pytest.mark.parametrize("w,h,seed", [(640, 480, 3), (131, 77, 3), (23, 310, 9)])
-def test_extrema_scan_forms_agree(oracle, gpu64, gpu32, w, h, seed, monkeypatch):
-    """The extrema scan has two forms: rows staged through LDS (the one normally launched) and rows loaded into
-    registers (for planes the staged form does not take; SIFTGPU_DETECT_DIRECT=1 selects it everywhere).  Both give
-    the oracle's counters and features in double, and identical features to each other in float and without the
-    neighbouring-layer comparison."""
+def test_staged_and_register_forms_agree(oracle, gpu64, gpu32, w, h, seed, monkeypatch):
+    """The blur and the extrema scan each have two forms: input rows staged through LDS by direct-to-LDS loads (the
+    ones normally launched) and rows loaded into registers (for planes whose rows are not 16-byte aligned;
+    SIFTGPU_BLUR_DIRECT=1 / SIFTGPU_DETECT_DIRECT=1 select them everywhere).  Both give the oracle's pyramid, counters
+    and features in double, and identical features to each other in float and without the neighbouring-layer
+    comparison."""
     import sift_amd
     img = oracle.vnoise5(w, h, seed)
     ref, _, ctr, _ = oracle.sift(img)
     results = []
     for direct in (False, True):
-        if direct:
-            monkeypatch.setenv("SIFTGPU_DETECT_DIRECT", "1")
-        else:
-            monkeypatch.delenv("SIFTGPU_DETECT_DIRECT", raising=False)
+        for var in ("SIFTGPU_DETECT_DIRECT", "SIFTGPU_BLUR_DIRECT"):
+            if direct:
+                monkeypatch.setenv(var, "1")
+            else:
+                monkeypatch.delenv(var, raising=False)
         got = gpu64.extract(img)
         assert gpu64.read_counters() == ctr, direct
+        if direct:
+            dbg = oracle.Debug(img)
+            for o in range(dbg.octaves):
+                for l in range(6):
+                    assert np.array_equal(gpu64.read_level(o, l), dbg.gauss[o * 6 + l]), "octave %d level %d" % (o, l)
         assert len(got) == len(ref)
         for f in FIELDS_EXACT:
             assert np.array_equal(got[f], ref[f]), (f, direct)

@@ -3,6 +3,8 @@
 #include "sg_internal.h"
 #include "sg_math.h"
 
+#include <type_traits>
+
 namespace sg {
 
 #define SG_PI 3.1415926535897932384626433832795 /* CV_PI */
@@ -102,53 +104,75 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
             // sample s -> (jj = s / W - radius: y offset; i = s % W - radius: x offset), so that neighbouring lanes
             // read neighbouring pixels (the reference walks x in its outer loop; the sums do not depend on it
             // beyond rounding)
-            int qj = lane / W, qi = lane - qj * W;
-            const int dq = 64 / W, dr = 64 - dq * W;
-            int i_n = 0, j_n = 0;
-            bool ok_n = false;
-            T nl = 0, nr = 0, nu = 0, nd = 0;
-            auto fetch = [&]() {
-                i_n = qi - radius;
-                j_n = qj - radius;
-                const int x = r.x + i_n, y = r.y + j_n;
-                ok_n = x > 0 && x < cols - 1 && y > 0 && y < rows - 1; // CalcGradMagOri's validity (sift.cpp:1115)
-                // the loads of an invalid sample are redirected to the nearest pixel that has four neighbours
-                const int xx = min(max(x, 1), cols - 2), yy = min(max(y, 1), rows - 2);
-                const unsigned int off = (unsigned int)yy * pitch_b + (unsigned int)xx * (unsigned int)sizeof(T);
-                const char *p8 = gb + (size_t)off;
-                nl = *reinterpret_cast<const T *>(p8 - sizeof(T));
-                nr = *reinterpret_cast<const T *>(p8 + sizeof(T));
-                nu = *reinterpret_cast<const T *>(p8 - (size_t)pitch_b);
-                nd = *reinterpret_cast<const T *>(p8 + (size_t)pitch_b);
-                qj += dq;
-                qi += dr;
-                if (qi >= W) {
-                    qi -= W;
-                    qj++;
+            // A window that lies inside the plane with a pixel to spare on every side (nearly all do) has a gradient
+            // at every sample: its walk needs neither the validity test nor the redirection of invalid samples.
+            const bool interior = r.x - radius > 0 && r.x + radius < cols - 1 && r.y - radius > 0 && r.y + radius < rows - 1;
+            auto walk = [&](auto interior_tag) {
+                constexpr bool INTERIOR = decltype(interior_tag)::value;
+                int qj = lane / W, qi = lane - qj * W;
+                const int dq = 64 / W, dr = 64 - dq * W;
+                int i_n = 0, j_n = 0;
+                bool ok_n = false;
+                T nl = 0, nr = 0, nu = 0, nd = 0;
+                auto fetch = [&]() {
+                    i_n = qi - radius;
+                    j_n = qj - radius;
+                    const int x = r.x + i_n, y = r.y + j_n;
+                    int xx = x, yy = y;
+                    if (!INTERIOR) {
+                        ok_n = x > 0 && x < cols - 1 && y > 0 && y < rows - 1; // CalcGradMagOri's validity (sift.cpp:1115)
+                        // the loads of an invalid sample are redirected to the nearest pixel that has four neighbours
+                        xx = min(max(x, 1), cols - 2);
+                        yy = min(max(y, 1), rows - 2);
+                    }
+                    const unsigned int off = (unsigned int)yy * pitch_b + (unsigned int)xx * (unsigned int)sizeof(T);
+                    const char *p8 = gb + (size_t)off;
+                    nl = *reinterpret_cast<const T *>(p8 - sizeof(T));
+                    nr = *reinterpret_cast<const T *>(p8 + sizeof(T));
+                    nu = *reinterpret_cast<const T *>(p8 - (size_t)pitch_b);
+                    nd = *reinterpret_cast<const T *>(p8 + (size_t)pitch_b);
+                    qj += dq;
+                    qi += dr;
+                    if (qi >= W) {
+                        qi -= W;
+                        qj++;
+                    }
+                };
+                if (lane < total)
+                    fetch();
+                for (int s = lane; s < total; s += 64) {
+                    const int i = i_n, jj = j_n;
+                    const bool ok = INTERIOR || ok_n;
+                    const double dx = (double)nr - (double)nl;
+                    const double dy = (double)nd - (double)nu;
+                    if (s + 64 < total)
+                        fetch();
+                    if (ok) {
+                        double mag = sg_sqrt(dx * dx + dy * dy);
+                        double ori = sg_atan2(dy, dx, centres);
+                        double weight;
+                        if (use_tab)
+                            weight = E[abs(i)] * E[abs(jj)];
+                        else
+                            weight = exp((i * i + jj * jj) * econs);
+                        // bin = cvRound(36 (pi - ori) / (2 pi)) (sift.cpp:1190).  The quotient is first taken as a
+                        // product with 1/(2 pi), a few ulp from the division; the two can round to different integers
+                        // only next to a half-integer, and there the division itself is evaluated.
+                        const double num = kOriBins * (SG_PI - ori);
+                        double quo = num * (1.0 / PI2);
+                        const bool near_half = fabs(fabs(quo - rint(quo)) - 0.5) < 1e-9;
+                        if (__ballot(near_half)) // wave-uniform, so that the division is skipped and not merely masked
+                            quo = near_half ? num / PI2 : quo;
+                        int bin = (int)rint(quo);
+                        bin = bin < kOriBins ? bin : 0;
+                        lds_add(&hc[bin], mag * weight);
+                    }
                 }
             };
-            if (lane < total)
-                fetch();
-            for (int s = lane; s < total; s += 64) {
-                const int i = i_n, jj = j_n;
-                const bool ok = ok_n;
-                const double dx = (double)nr - (double)nl;
-                const double dy = (double)nd - (double)nu;
-                if (s + 64 < total)
-                    fetch();
-                if (ok) {
-                    double mag = sg_sqrt(dx * dx + dy * dy);
-                    double ori = sg_atan2(dy, dx, centres);
-                    double weight;
-                    if (use_tab)
-                        weight = E[abs(i)] * E[abs(jj)];
-                    else
-                        weight = exp((i * i + jj * jj) * econs);
-                    int bin = (int)rint(kOriBins * (SG_PI - ori) / PI2);
-                    bin = bin < kOriBins ? bin : 0;
-                    lds_add(&hc[bin], mag * weight);
-                }
-            }
+            if (interior)
+                walk(std::true_type{});
+            else
+                walk(std::false_type{});
         }
         wave_lds_fence();
         const bool binlane = lane < kOriBins;

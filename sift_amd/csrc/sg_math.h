@@ -51,9 +51,12 @@ __device__ __forceinline__ double sg_div(double n, double d)
 // `centres` is a 5-entry table of (c, caller's multiple of k) pairs, normally in LDS (sg_atan_centres_fill).
 __device__ __forceinline__ double sg_atan_split(double mn, double mx, const double2 *centres, double &k_term)
 {
-    int k = (mn > 0.09849140335716425 * mx ? 1 : 0) + (mn > 0.30334668360734239 * mx ? 1 : 0) +
-            (mn > 0.53451113595079158 * mx ? 1 : 0) + (mn > 0.82067879082866024 * mx ? 1 : 0);
-    const double2 ck = centres[k];
+    // the thresholds ascend, so the last one passed gives k; formed as the entry's byte offset (one select each)
+    unsigned int koff = mn > 0.09849140335716425 * mx ? 16u : 0u;
+    koff = mn > 0.30334668360734239 * mx ? 32u : koff;
+    koff = mn > 0.53451113595079158 * mx ? 48u : koff;
+    koff = mn > 0.82067879082866024 * mx ? 64u : koff;
+    const double2 ck = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(centres) + koff);
     k_term = ck.y;
     const double num = __builtin_fma(-ck.x, mx, mn);
     const double den = fmax(__builtin_fma(ck.x, mn, mx), 1e-300);

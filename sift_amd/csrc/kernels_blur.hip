@@ -420,7 +420,23 @@ constexpr int win_waves_per_simd(int R) { return R <= 6 ? SG_WIN_WPE6 : (R <= 8 
 // hand-offs; worth its registers only at the widest radius, whose kernel runs at two waves per SIMD anyway.
 constexpr int win_rows_per_iter(int R) { return R > 10 ? 4 : 2; }
 
-template <typename T, int R, int V, bool UPS = false>
+// Gray rows of the upsampling form staged by direct-to-LDS loads (GDMA): geometry of a wave's ring.
+template <typename T, int R, int V>
+struct WinGray {
+    static constexpr int TW = 64 * V, KR = win_rows_per_iter(R);
+    static constexpr int FRONT = (R + 3) / 2 + 1 + ((R + 3) / 2 + 1) % 2; // gray columns in front of the strip's first (even)
+    static constexpr int GCOLS = FRONT + TW / 2 + (R + 1) / 2 + 2;         // gray columns a row image must hold
+    static constexpr int NP = (GCOLS + 1) / 2;                             // 16-byte pieces (two doubles) per gray row
+    static constexpr int NI = (NP + 63) / 64;                              // load instructions per gray row
+    static constexpr int ROWB = NP * 16, ROWE = NP * 2;
+    static constexpr int DI = 3;                                           // iterations in the ring
+    static constexpr int SLOTB = KR * 2 * ROWB;                            // two gray rows per output row
+    static constexpr int WAVE_BYTES = DI * SLOTB;
+    static constexpr int PER = KR * 2 * NI;                                // load instructions per iteration
+    static_assert((DI - 1) * PER < 64, "outstanding loads fit the counter");
+};
+
+template <typename T, int R, int V, bool UPS = false, bool GDMA = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(win_waves_per_simd(R), win_waves_per_simd(R))))
 void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols, int spitch, int dpitch, size_t simg,
                 size_t dimg, int seg, Taps<T> taps, T *__restrict__ dec, int dec_rows, int dec_cols, int dec_pitch,
@@ -433,6 +449,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
     constexpr int NWIN = (V + 2 * R + V - 1) / V;      // vectors per row window
     constexpr int RAWW = (R + TW + NWIN * V + 3) & ~3; // raw row image incl. read overshoot, 16-byte rows
     static_assert(KR % 2 == 0, "row parity inside an iteration is the image's");
+    static_assert(!GDMA || UPS, "the gray ring belongs to the upsampling form");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     T *raw = reinterpret_cast<T *>(smem_raw) + (size_t)wave * KR * RAWW;
@@ -467,6 +484,34 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
     // columns repeat row rows-3 and column cols-3), i = Y'/2, j = X'/2:  s(i,j) | (s(i,j)+s(i,j+1))/2 |
     // (s(i,j)+s(i+1,j))/2 | (s(i+1,j)+s(i,j)+s(i+1,j+1)+s(i,j+1))/4  by the parities of Y' and X'.
     const double *gsrc = reinterpret_cast<const double *>(src) + blockIdx.z * simg;
+    // GDMA: the gray rows an iteration needs (two per output row: i = Y'/2 and i + 1) are staged into a wave-private
+    // LDS ring by direct-to-LDS loads, DI iterations ahead, and the upsampled pixels are formed from there; a gray row
+    // image starts FRONT columns left of the strip's first gray column (an even column: 16-byte pieces are aligned).
+    using GR = WinGray<T, R, V>;
+    constexpr int kRawBytes = (4 * KR * RAWW * (int)sizeof(T) + 15) & ~15;
+    const int jb = (x0 >> 1) - GR::FRONT; // gray column of element 0 of a row image
+    const double *gring = reinterpret_cast<const double *>(smem_raw + kRawBytes + (size_t)wave * GR::WAVE_BYTES);
+    const unsigned int lds_gring = (unsigned int)(uintptr_t)smem_raw + (unsigned int)kRawBytes + (unsigned int)wave * GR::WAVE_BYTES;
+    unsigned int gvoff[GR::NI];
+#pragma unroll
+    for (int q = 0; q < GR::NI; q++)
+        gvoff[q] = (unsigned int)min(max(jb + 2 * (lane + 64 * q), 0), spitch - 2) * 8u;
+    auto stage_gray = [&](int t) { // iteration t's gray rows into slot t mod DI
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const int yy = reflect101_once(ys - R + KR * t + k, rows);
+            const int gi = min(yy, rows - 3) >> 1;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned long long base = (unsigned long long)(uintptr_t)(gsrc + (size_t)(gi + h) * spitch);
+                const unsigned int to = lds_gring + (unsigned int)((t % GR::DI) * GR::SLOTB + (k * 2 + h) * GR::ROWB);
+#pragma unroll
+                for (int q = 0; q < GR::NI; q++)
+                    if (q + 1 < GR::NI || lane < GR::NP - 64 * (GR::NI - 1))
+                        load16_to_lds(to + 1024u * q, base, gvoff[q]);
+            }
+        }
+    };
     int uj[V], uo[V]; // j and column parity of the lane's elements, and of its halo column
 #pragma unroll
     for (int q = 0; q < V; q++) {
@@ -492,7 +537,14 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
             if (UPS) {
                 const int yc = min(yy, rows - 3);
                 const bool oddr = (yc & 1) != 0; // wave-uniform
-                const double *g0 = gsrc + (size_t)(yc >> 1) * spitch, *g1 = g0 + spitch;
+                const double *g0, *g1;
+                if (GDMA) { // element 0 of a staged row is gray column jb
+                    g0 = gring + ((t % GR::DI) * (GR::SLOTB / 8) + (k * 2) * GR::ROWE) - jb;
+                    g1 = g0 + GR::ROWE;
+                } else {
+                    g0 = gsrc + (size_t)(yc >> 1) * spitch;
+                    g1 = g0 + spitch;
+                }
                 T *pv = reinterpret_cast<T *>(&mainv[k]);
                 if (strip_inner) {
                     // the V elements are (even, odd) column pairs over V/2 source columns
@@ -538,6 +590,12 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
         for (int e = 0; e < V; e++)
             pw[e] = (T)0;
     }
+    if (GDMA) {
+        static_assert(!GDMA || PF == 1, "one fetch per iteration, for the next one");
+        for (int t = 0; t < min(GR::DI, n_iter); t++)
+            stage_gray(t);
+        wait_groups_ahead<GR::PER, GR::DI - 1>(n_iter - 1);
+    }
 #pragma unroll
     for (int p = 0; p < PF; p++)
         if (p < n_iter)
@@ -570,8 +628,14 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                 halo_s[p][k] = halo_s[p + 1][k];
             }
         }
-        if (t + PF < n_iter)
+        // slot t mod DI held this iteration's gray rows: the stores above consumed what was read from it
+        if (GDMA && t + GR::DI < n_iter)
+            stage_gray(t + GR::DI);
+        if (t + PF < n_iter) {
+            if (GDMA) // iterations t+2 .. t+DI (those that exist) may stay in flight
+                wait_groups_ahead<GR::PER, GR::DI - 1>(n_iter - 1 - (t + PF));
             fetch(t + PF, mainv_s[PF - 1], halo_s[PF - 1]);
+        }
 #pragma unroll
         for (int k = 0; k < KR; k++) {
             vec_t o;
@@ -1197,9 +1261,18 @@ static bool ups_dispatch(const Plane &gray, const Plane &dst, int B, const doubl
     const int seg = win_segment_rows(rows, per_row, R, win_waves_per_simd(R));
     const int nseg = (rows + seg - 1) / seg;
     dim3 g((strips + 3) / 4, nseg, B);
-    blur_win_k<T, R, V, true><<<g, 256, win_lds_bytes<T, R, V>(), s>>>(
-        (const T *)gray.p, (T *)dst.p, rows, cols, gray.pitch, dst.pitch, gray.img_stride, dst.img_stride, seg,
-        padded_taps<T>(taps, n, R), nullptr, 0, 0, 0, 0);
+    // gray rows staged by direct-to-LDS loads when they are 16-byte aligned (SIFTGPU_BLUR_DIRECT=1: loaded by the lanes)
+    const bool gdma = !getenv("SIFTGPU_BLUR_DIRECT") && (uintptr_t)gray.p % 16 == 0 && gray.pitch % 2 == 0 &&
+                      gray.pitch >= 2 && (gray.img_stride * sizeof(double)) % 16 == 0;
+    if (gdma)
+        blur_win_k<T, R, V, true, true>
+            <<<g, 256, ((win_lds_bytes<T, R, V>() + 15) & ~(size_t)15) + 4 * WinGray<T, R, V>::WAVE_BYTES, s>>>(
+                (const T *)gray.p, (T *)dst.p, rows, cols, gray.pitch, dst.pitch, gray.img_stride, dst.img_stride, seg,
+                padded_taps<T>(taps, n, R), nullptr, 0, 0, 0, 0);
+    else
+        blur_win_k<T, R, V, true><<<g, 256, win_lds_bytes<T, R, V>(), s>>>(
+            (const T *)gray.p, (T *)dst.p, rows, cols, gray.pitch, dst.pitch, gray.img_stride, dst.img_stride, seg,
+            padded_taps<T>(taps, n, R), nullptr, 0, 0, 0, 0);
     return true;
 }
 

@@ -3,6 +3,7 @@
 #include "sg_internal.h"
 #include "sg_math.h"
 
+#include <stddef.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -725,7 +726,8 @@ void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int 
 }
 
 // ---- output packing ------------------------------------------------------------------------------------------
-// One wave per feature; position = rank (sorted) or emission index.
+// Position = rank (sorted) or emission index.  MODE 0: packed records, 16 lanes per feature; MODE 1: sg_keypoint
+// records and MODE 2: packed records at an unaligned address, one wave per feature.
 template <int MODE>
 __global__ __launch_bounds__(256) void pack_k(const KpRec *kp, size_t kp_img, const unsigned int *kp_src, size_t src_img,
                                               const unsigned int *feat_src, size_t fsrc_img,
@@ -743,6 +745,32 @@ __global__ __launch_bounds__(256) void pack_k(const KpRec *kp, size_t kp_img, co
         if (n > out_cap)
             atomicMax(overflow, n);
     }
+    if (MODE == 0) {
+        // 16 lanes per feature, so that a wave follows four index chains at a time: lanes 0..7 of a group copy the
+        // descriptor in 16-byte pieces, lane 8 writes the 16-byte header
+        const int sub = threadIdx.x & 15;
+        for (unsigned int f = blockIdx.x * 16u + (threadIdx.x >> 4); f < n; f += gridDim.x * 16u) {
+            const unsigned int pos = sorted ? rank[(size_t)b * rank_img + f] : f;
+            if (pos >= out_cap)
+                continue;
+            sg_packed_feature *o = reinterpret_cast<sg_packed_feature *>(out) + (size_t)b * out_img + pos;
+            static_assert(sizeof(sg_packed_feature) == 144 && offsetof(sg_packed_feature, desc) == 16,
+                          "16-byte header, then the descriptor");
+            if (sub < 8) {
+                const uint4 v = reinterpret_cast<const uint4 *>(desc + (size_t)b * desc_img + (size_t)f * 128)[sub];
+                reinterpret_cast<uint4 *>(o->desc)[sub] = v;
+            } else if (sub == 8) {
+                const unsigned int fs = feat_src[(size_t)b * fsrc_img + f];
+                const unsigned int j = fs >> 6, pbin = fs & 63;
+                const KpRec *r = kp + (size_t)b * kp_img + kp_src[(size_t)b * src_img + j];
+                const double ori = ori_tmp[(size_t)b * ori_img + (size_t)j * kOriBins + pbin];
+                float4 h;
+                h.x = (float)r->dx; h.y = (float)r->dy; h.z = (float)r->scale; h.w = (float)ori;
+                *reinterpret_cast<float4 *>(o) = h;
+            }
+        }
+        return;
+    }
     for (unsigned int f = blockIdx.x * 4u + (threadIdx.x >> 6); f < n; f += gridDim.x * 4u) {
         const unsigned int pos = sorted ? rank[(size_t)b * rank_img + f] : f;
         if (pos >= out_cap)
@@ -752,7 +780,7 @@ __global__ __launch_bounds__(256) void pack_k(const KpRec *kp, size_t kp_img, co
         const KpRec r = kp[(size_t)b * kp_img + kp_src[(size_t)b * src_img + j]];
         const double ori = ori_tmp[(size_t)b * ori_img + (size_t)j * kOriBins + pbin];
         const uint8_t *d = desc + (size_t)b * desc_img + (size_t)f * 128;
-        if (MODE == 0) {
+        if (MODE != 1) { // MODE 2: packed records at an address that is not a multiple of 16
             sg_packed_feature *o = reinterpret_cast<sg_packed_feature *>(out) + (size_t)b * out_img + pos;
             if (lane < 32)
                 reinterpret_cast<uint32_t *>(o->desc)[lane] = reinterpret_cast<const uint32_t *>(d)[lane];
@@ -781,14 +809,18 @@ void launch_pack(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_s
                  unsigned int out_cap, unsigned int *out_counts, unsigned int *overflow, int mode, int sorted,
                  unsigned int cap, int B, hipStream_t s)
 {
-    unsigned int blocks = (cap + 3) / 4;
+    unsigned int blocks = mode == 0 ? (cap + 15) / 16 : (cap + 3) / 4;
     if (blocks > 2048)
         blocks = 2048;
     if (blocks == 0)
         blocks = 1;
     dim3 g(blocks, B);
-    if (mode == 0)
+    if (mode == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)desc % 16 == 0 && desc_img_stride % 16 == 0)
         pack_k<0><<<g, 256, 0, s>>>(kp, kp_img_stride, kp_src, src_img_stride, feat_src, fsrc_img_stride, feat_count,
+                                    ori_tmp, ori_img_stride, desc, desc_img_stride, rank, rank_img_stride, out,
+                                    out_img_stride, out_cap, out_counts, overflow, sorted, cap);
+    else if (mode == 0)
+        pack_k<2><<<g, 256, 0, s>>>(kp, kp_img_stride, kp_src, src_img_stride, feat_src, fsrc_img_stride, feat_count,
                                     ori_tmp, ori_img_stride, desc, desc_img_stride, rank, rank_img_stride, out,
                                     out_img_stride, out_cap, out_counts, overflow, sorted, cap);
     else

@@ -211,6 +211,33 @@ def test_batch_device_matches_single(oracle, gpu64):
         assert out[i, : cnt[i]].tobytes() == packed[i].tobytes()
 
 
+def test_batch_device_output_at_unaligned_address(oracle, gpu64):
+    """Packed records are 4-byte aligned by type; an output buffer that does not start on a 16-byte boundary takes
+    the packing kernel's other form and gives the same records."""
+    import sift_amd
+    w, h, n, cap = 160, 120, 2, 2048
+    imgs = np.stack([oracle.vnoise5(w, h, 300 + i) for i in range(n)])
+    packed = gpu64.extract_batch(imgs, cap)
+    d_img = gpu64.malloc(n * w * h * 3)
+    d_out = gpu64.malloc(n * cap * 144 + 16)
+    d_cnt = gpu64.malloc(n * 4)
+    try:
+        gpu64.h2d(d_img, imgs)
+        gpu64.extract_batch_device(d_img, n, w, h, 3, d_out + 4, cap, d_cnt)
+        gpu64.sync()
+        cnt = np.zeros(n, dtype=np.uint32)
+        gpu64.d2h(cnt, d_cnt)
+        out = np.zeros((n, cap), dtype=sift_amd.PACKED_DTYPE)
+        gpu64.d2h(out, d_out + 4)
+    finally:
+        gpu64.free(d_img)
+        gpu64.free(d_out)
+        gpu64.free(d_cnt)
+    for i in range(n):
+        assert cnt[i] == len(packed[i])
+        assert out[i, : cnt[i]].tobytes() == packed[i].tobytes()
+
+
 def test_flat_image_has_no_features(gpu64):
     img = np.full((64, 64, 3), 128, dtype=np.uint8)
     assert len(gpu64.extract(img)) == 0

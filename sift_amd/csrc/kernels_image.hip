@@ -14,16 +14,61 @@ __device__ __forceinline__ double gray_of(const uint8_t *p)
     return b * 0.114 + g * 0.587 + r * 0.299;
 }
 
-template <typename T>
+// A channel value has 256 possibilities, so each block tabulates (v/255.0)*weight for the three channels once (the
+// same operations on the same operands as gray_of, hence the same doubles) and a pixel costs three LDS reads and two
+// additions in gray_of's order.  A thread takes four neighbouring pixels of a row: with three interleaved channels
+// and 4-byte aligned rows (QUADS) their 12 bytes are three dword loads.
+template <typename T, bool QUADS>
 __global__ __launch_bounds__(256) void gray_k(const uint8_t *src, int rows, int cols, int ch, size_t stride,
-                                              size_t img_stride, T *dst, int dpitch, size_t dimg)
+                                              size_t img_stride, T *dst, int dpitch, size_t dimg, int vec_store)
 {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ double tab[3][256];
+    {
+        const double v = threadIdx.x / 255.0;
+        tab[0][threadIdx.x] = v * 0.114;
+        tab[1][threadIdx.x] = v * 0.587;
+        tab[2][threadIdx.x] = v * 0.299;
+    }
+    __syncthreads();
+    const int x = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= cols || y >= rows)
         return;
     const uint8_t *s = src + blockIdx.z * img_stride + stride * (size_t)y + (size_t)ch * x;
-    dst[blockIdx.z * dimg + (size_t)y * dpitch + x] = (T)gray_of(s);
+    T *d = dst + blockIdx.z * dimg + (size_t)y * dpitch + x;
+    T out[4];
+    if (QUADS && x + 4 <= cols) {
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(s);
+        const uint32_t w0 = w[0], w1 = w[1], w2 = w[2]; // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+        out[0] = (T)(tab[0][w0 & 255u] + tab[1][(w0 >> 8) & 255u] + tab[2][(w0 >> 16) & 255u]);
+        out[1] = (T)(tab[0][w0 >> 24] + tab[1][w1 & 255u] + tab[2][(w1 >> 8) & 255u]);
+        out[2] = (T)(tab[0][(w1 >> 16) & 255u] + tab[1][w1 >> 24] + tab[2][w2 & 255u]);
+        out[3] = (T)(tab[0][(w2 >> 8) & 255u] + tab[1][(w2 >> 16) & 255u] + tab[2][w2 >> 24]);
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (x + q < cols)
+                out[q] = (T)(tab[0][s[ch * q]] + tab[1][s[ch * q + 1]] + tab[2][s[ch * q + 2]]);
+    }
+    // vec_store: rows start on 16-byte boundaries and dpitch is a multiple of four elements, like x: the four outputs
+    // are one aligned group (the pad columns behind a row's end may be written)
+    if (vec_store && x + 4 <= dpitch) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (x + q >= cols)
+                out[q] = (T)0;
+        if (sizeof(T) == 8) {
+            reinterpret_cast<double2 *>(d)[0] = make_double2((double)out[0], (double)out[1]);
+            reinterpret_cast<double2 *>(d)[1] = make_double2((double)out[2], (double)out[3]);
+        } else {
+            reinterpret_cast<float4 *>(d)[0] = make_float4((float)out[0], (float)out[1], (float)out[2], (float)out[3]);
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (x + q < cols)
+                d[q] = out[q];
+    }
 }
 
 // UpSample (reference sift/sift.cpp:111-175).  One thread per source cell (i,j), i < R-1, j < C-1,
@@ -127,11 +172,19 @@ static inline dim3 grid2d(int cols, int rows, int B) { return dim3((cols + 63) /
 void launch_gray(const uint8_t *src, int rows, int cols, int ch, size_t stride, size_t img_stride,
                  const Plane &dst, int B, int prec, hipStream_t s)
 {
-    dim3 g = grid2d(cols, rows, B);
-    if (prec == SG_F64)
-        gray_k<double><<<g, 256, 0, s>>>(src, rows, cols, ch, stride, img_stride, (double *)dst.p, dst.pitch, dst.img_stride);
-    else
-        gray_k<float><<<g, 256, 0, s>>>(src, rows, cols, ch, stride, img_stride, (float *)dst.p, dst.pitch, dst.img_stride);
+    dim3 g((cols + 255) / 256, (rows + 3) / 4, B);
+    // dword loads of the channel bytes: three interleaved channels and rows that start on 4-byte boundaries
+    const bool quads = ch == 3 && (uintptr_t)src % 4 == 0 && stride % 4 == 0 && img_stride % 4 == 0;
+    const bool vec_ok = dst.pitch % 4 == 0 && (uintptr_t)dst.p % 16 == 0 && dst.img_stride % 4 == 0;
+#define SG_GRAY(TT, QQ)                                                                                               \
+    gray_k<TT, QQ><<<g, 256, 0, s>>>(src, rows, cols, ch, stride, img_stride, (TT *)dst.p, dst.pitch,                \
+                                     dst.img_stride, vec_ok ? 1 : 0)
+    if (prec == SG_F64) {
+        if (quads) SG_GRAY(double, true); else SG_GRAY(double, false);
+    } else {
+        if (quads) SG_GRAY(float, true); else SG_GRAY(float, false);
+    }
+#undef SG_GRAY
 }
 
 void launch_upsample(const Plane &src, const Plane &dst, int B, int prec, hipStream_t s)

@@ -87,7 +87,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="frames per step per GPU")
+    ap.add_argument("--batch", type=int, default=256,
+                    help="frames per step per GPU (the f64 pyramid of a 1080p frame takes 0.53 GB; halved until the\n"
+                         "context fits when the device has less memory free)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64")
@@ -133,8 +135,16 @@ def main():
     prec = sift_amd.SG_F64 if args.precision == "f64" else sift_amd.SG_F32
     esize = 8 if prec == sift_amd.SG_F64 else 4
     nctx = max(1, min(args.contexts, 4))
-    ctxs = [sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=B, precision=prec, device=dev_index)
-            for _ in range(nctx)]
+    ctxs = None
+    while ctxs is None:
+        try:
+            ctxs = [sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=B, precision=prec, device=dev_index)
+                    for _ in range(nctx)]
+        except sift_amd.SiftGpuError as e:  # not enough device memory for this many frames in flight
+            if e.status != sift_amd.api.SG_E_NOMEM or B <= 8:
+                raise
+            ctxs = None
+            B //= 2
 
     # ---- synthetic frames, generated on the device, resident in HBM ----
     pool = max(B, min(args.pool, (K + WU) * B))

@@ -41,8 +41,12 @@ def pmc(kind):
 
 fetch, write = pmc("fetch"), pmc("write")
 rows = list(csv.DictReader(open(stats)))
-traffic = {"_config": {"batch": 64, "width": 1920, "height": 1080, "precision": "f64", "command": "python bench.py"}}
-lines = ["# rocprofv3 summary (%s): `python bench.py` (4 steps x 64 frames 1920x1080, f64, one context)" % tag, "",
+try:
+    _batch = json.load(open(os.path.join(src, "bench_stats.json")))["config"]["batch"]
+except (OSError, ValueError, KeyError):
+    _batch = 256
+traffic = {"_config": {"batch": _batch, "width": 1920, "height": 1080, "precision": "f64", "command": "python bench.py"}}
+lines = ["# rocprofv3 summary (%s): `python bench.py` (4 steps x %d frames 1920x1080, f64, one context)" % (tag, _batch), "",
          "| kernel | calls | avg us | total ms | % | FETCH_SIZE MB/launch (x2 for blur and detect) | WRITE_SIZE MB/launch |", "|---|---|---|---|---|---|---|"]
 for r in rows[:24]:
     k = short(r["Name"])

@@ -135,16 +135,36 @@ def main():
     prec = sift_amd.SG_F64 if args.precision == "f64" else sift_amd.SG_F32
     esize = 8 if prec == sift_amd.SG_F64 else 4
     nctx = max(1, min(args.contexts, 4))
+    def buffers_bytes(b):
+        """Device memory this script allocates beside the contexts: the resident frames, the packed-feature buffers
+        and, with more than one rank, the gathered ones."""
+        nb = nctx if world == 1 else max(2, nctx)
+        pool_frames = max(b, min(args.pool, (K + WU) * b))
+        return pool_frames * W * H * 3 + nb * b * args.cap * 144 * (1 + (world if world > 1 else 0)) + (1 << 30)
+
     ctxs = None
     while ctxs is None:
         try:
             ctxs = [sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=B, precision=prec, device=dev_index)
                     for _ in range(nctx)]
+            if torch.cuda.mem_get_info(dev)[0] < buffers_bytes(B) and B > 8:
+                raise sift_amd.SiftGpuError(sift_amd.api.SG_E_NOMEM, "no room left for the frame and feature buffers")
         except sift_amd.SiftGpuError as e:  # not enough device memory for this many frames in flight
             if e.status != sift_amd.api.SG_E_NOMEM or B <= 8:
                 raise
+            for c in ctxs or []:
+                c.close()
             ctxs = None
             B //= 2
+    if world > 1:  # every rank takes the same number of frames per step: the smallest any rank could fit
+        agreed = torch.tensor([B], dtype=torch.int64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) != B:
+            B = int(agreed.item())
+            for c in ctxs:
+                c.close()
+            ctxs = [sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=B, precision=prec, device=dev_index)
+                    for _ in range(nctx)]
 
     # ---- synthetic frames, generated on the device, resident in HBM ----
     pool = max(B, min(args.pool, (K + WU) * B))

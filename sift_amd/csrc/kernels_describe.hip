@@ -230,9 +230,10 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
 // Every workgroup pays a start-up (two dependent loads before the first record is there, tables, constants) and only
 // a wave that takes several entries can load the next record while it works on the current one, so a launch holds a
 // fixed number of waves in all -- waves_per_cu for every compute unit, a few rounds of the resident waves, enough to
-// even out the differences between windows -- whatever the list lengths.  (With one wave per entry the orientation
+// even out the differences between windows -- and at least min_per_image per image, whatever the list lengths.  (With one wave per entry the orientation
 // kernel ran 30 % longer.)  The environment variable overrides the total, for experiments.
-static unsigned int feature_blocks(unsigned int cap, int B, unsigned int waves_per_cu, const char *env)
+static unsigned int feature_blocks(unsigned int cap, int B, unsigned int waves_per_cu, unsigned int min_per_image,
+                                   const char *env)
 {
     static const unsigned int n_cu = [] {
         int dev = 0, cu = 0;
@@ -245,8 +246,8 @@ static unsigned int feature_blocks(unsigned int cap, int B, unsigned int waves_p
     if (const char *e = getenv(env))
         total = (unsigned int)atoi(e);
     unsigned int blocks = total / (unsigned int)(B > 0 ? B : 1);
-    if (blocks < 64)
-        blocks = 64;
+    if (blocks < min_per_image) // large batches: a wave still takes no more than a few dozen entries of an image
+        blocks = min_per_image;
     return blocks < cap ? blocks : cap;
 }
 
@@ -255,7 +256,7 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
                    unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
                    size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec, hipStream_t s)
 {
-    unsigned int blocks = feature_blocks(cap, B, 64, "SIFTGPU_ORI_WAVES");
+    unsigned int blocks = feature_blocks(cap, B, 64, 256, "SIFTGPU_ORI_WAVES");
     if (blocks == 0)
         return;
     dim3 g(blocks, B);
@@ -579,7 +580,7 @@ void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_str
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
                   int max_radius, int B, int prec, hipStream_t s)
 {
-    unsigned int blocks = feature_blocks(cap, B, 384, "SIFTGPU_DESCR_WAVES");
+    unsigned int blocks = feature_blocks(cap, B, 384, 384, "SIFTGPU_DESCR_WAVES");
     if (blocks == 0)
         return;
     dim3 g(blocks, B);

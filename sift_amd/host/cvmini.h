@@ -1,11 +1,13 @@
 // cvmini.h -- the few cv:: types the SIFT entry points take, for builds without OpenCV.
 //
 // The reference's interface (sift/sift.h) passes images as cv::Mat and uses it only as a 2-D buffer:
-// rows, cols, data, step, dataend, create(), copyTo(), clone(), empty(), size(), type(), channels().
+// rows, cols, data, step, dataend, create(), copyTo(), clone(), empty(), size(), type(), channels()
+// (and cv::Point, cv::Scalar, CV_RGB for its drawing helpers).
 // This header provides exactly that much, with reference counting like cv::Mat's shallow copies.
 // Define SIFT_WITH_OPENCV before including sift_gpu.h to use the real OpenCV types instead.
 #pragma once
 
+#include <cmath>
 #include <cstddef>
 #include <cstdlib>
 #include <cstring>
@@ -31,6 +33,30 @@ struct Size {
     Size() {}
     Size(int w, int h) : width(w), height(h) {}
 };
+
+struct Point {
+    int x = 0, y = 0;
+    Point() {}
+    // like cv::Point's converting constructor: floating coordinates are rounded (cv::saturate_cast<int>)
+    template <typename A, typename B>
+    Point(A px, B py) : x(round_to_int(px)), y(round_to_int(py)) {}
+
+private:
+    static int round_to_int(int v) { return v; }
+    static int round_to_int(double v) { return (int)std::lrint(v); }
+};
+
+struct Scalar {
+    double val[4] = {0, 0, 0, 0};
+    Scalar() {}
+    Scalar(double v0, double v1 = 0, double v2 = 0, double v3 = 0)
+    {
+        val[0] = v0; val[1] = v1; val[2] = v2; val[3] = v3;
+    }
+};
+#ifndef CV_RGB
+#define CV_RGB(r, g, b) cv::Scalar((b), (g), (r), 0)
+#endif
 
 class Mat {
 public:

@@ -7,8 +7,9 @@
 //   plus CalculateScale, HalfFeatures, OrientationAssignment, DescriptorRepresentation, FeatureCmp
 //   (defined with external linkage in the reference's sift.cpp:1065-1643 though absent from its header)
 //   and the text feature files (write_features / read_features, sift.cpp:1886-1931).
-// Not provided (outside the extraction path): the 8-bit legacy blurs, drawing, pyramid dumps and
-// testInverse3D of the reference (sift.cpp:183-314, 1772-1884, 1934-1960).
+//   and the drawing and pyramid-dump helpers (sift.cpp:1772-1884; host code, no GPU involved).
+// Not provided (outside the extraction path): the 8-bit legacy blurs and testInverse3D of the reference
+// (sift.cpp:183-314, 1934-1960).
 //
 // Like the reference these functions return void and append to the vectors they are given; a failed
 // GPU call leaves the outputs untouched and is reported by SiftLastStatus() / SiftLastError().
@@ -110,6 +111,18 @@ void write_features(const std::vector<Keypoint> &features, const char *file);
 // reproduced).  Output in index_1 order.
 void MatchFeatures(const std::vector<Keypoint> &features1, const std::vector<Keypoint> &features2,
                    std::vector<MatchPoint> &matches, double ratio = 0.5);
+
+// ---- drawing and pyramid dumps (sift.h:143-153, sift.cpp:1772-1884); host code -----------------------------------
+// Drawing works on CV_8UC3 images.  Without OpenCV the lines are 8-connected Bresenham lines and the circles midpoint
+// circles of thickness 1, clipped to the image (OpenCV's own rasteriser may choose other pixels on a tie), and
+// writecv64f / write_pyr write binary PGM files (`<dir><i>.pgm`) where the reference writes JPEG through cv::imwrite.
+void DrawSiftFeature(Mat &src, Keypoint &feat, cv::Scalar color); // arrow of length 5*scale along ori (sift.cpp:1772-1806)
+void DrawSiftFeatures(Mat &src, std::vector<Keypoint> &features); // green arrows (sift.cpp:1808-1815)
+void DrawKeyPoints(Mat &src, std::vector<Keypoint> &keypoints);   // blue circles of radius 3 at (dx, dy) (sift.cpp:1817-1827)
+void DrawKeyPointsRight(Mat &src, std::vector<Keypoint> &keypoints, cv::Size size); // ... shifted right by size.width
+void cv64f_to_cv8U(const Mat &src, Mat &dst);          // min-max normalised to 0..255, rounded (sift.cpp:1843-1847)
+void writecv64f(const char *filename, const Mat &mat); // cv64f_to_cv8U, then the image file (sift.cpp:1858-1863)
+void write_pyr(const std::vector<Mat> &pyr, const char *dir); // every level as <dir><i>.pgm (sift.cpp:1865-1873)
 
 // ---- additions of this implementation -----------------------------------------------------------------------
 int SiftLastStatus();            // sg_status of the most recent call on this thread (0 = ok)

@@ -138,7 +138,11 @@ void launch_pack(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_s
 // n_pad = n rounded up to 32 (at least 32).  mode 0: sg_packed_feature records, 1: sg_keypoint records.
 void launch_match_prep(const void *feats, int mode, unsigned int n, unsigned int n_pad, signed char *rows, int *norms,
                        unsigned int *bad, hipStream_t s);
+// partials: room for n1 (rounded up to 32) * kMatchMaxSlices * 12 bytes; slices from match_slices (1: partials unused)
+constexpr unsigned int kMatchMaxSlices = 16;
+unsigned int match_slices(unsigned int n1, unsigned int n2);
 void launch_match(const signed char *rows1, const int *norms1, unsigned int n1, const signed char *rows2,
-                  const int *norms2, unsigned int n2, double ratio, int *index2, unsigned int *dist2, hipStream_t s);
+                  const int *norms2, unsigned int n2, double ratio, int *index2, unsigned int *dist2, void *partials,
+                  unsigned int slices, hipStream_t s);
 
 } // namespace sg

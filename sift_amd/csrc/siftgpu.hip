@@ -49,6 +49,8 @@ struct sg_ctx {
     int *d_mnorm[2] = {nullptr, nullptr};
     unsigned int m_cap[2] = {0, 0};
     unsigned int *d_mbad = nullptr;
+    void *d_mpart = nullptr; // per-slice partial results of the matcher
+    size_t mpart_bytes = 0;
 
     // geometry of the current call
     int w = 0, h = 0, octaves = 0, last_batch = 0;
@@ -601,7 +603,7 @@ int sg_destroy(sg_ctx *c)
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
-    void *mbufs[] = {c->d_mrows[0], c->d_mrows[1], c->d_mnorm[0], c->d_mnorm[1], c->d_mbad,
+    void *mbufs[] = {c->d_mrows[0], c->d_mrows[1], c->d_mnorm[0], c->d_mnorm[1], c->d_mbad, c->d_mpart,
                      c->d_taps[0], c->d_taps[1], c->d_taps[2], c->d_taps[3], c->d_taps[4], c->d_taps[5]};
     for (void *b : mbufs)
         if (b)
@@ -1087,6 +1089,18 @@ static int match_prepare(sg_ctx *c, int which, const void *d_feats, int mode, si
         HIPCHK(c, hipMemsetAsync(c->d_mbad, 0, sizeof(unsigned int), c->stream));
     }
     launch_match_prep(d_feats, mode, (unsigned int)n, n_pad, c->d_mrows[which], c->d_mnorm[which], c->d_mbad, c->stream);
+    if (which == 0) { // room for the partial results of n features of image 1
+        const size_t need = (size_t)n_pad * kMatchMaxSlices * 12;
+        if (need > c->mpart_bytes) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_mpart)
+                (void)hipFree(c->d_mpart);
+            c->d_mpart = nullptr;
+            c->mpart_bytes = 0;
+            HIPCHK(c, hipMalloc(&c->d_mpart, need));
+            c->mpart_bytes = need;
+        }
+    }
     return SG_OK;
 }
 
@@ -1102,7 +1116,8 @@ int sg_match_packed_device(sg_ctx *c, const sg_packed_feature *d_f1, uint32_t n1
     rc = match_prepare(c, 1, d_f2, 0, n2);
     if (rc != SG_OK)
         return rc;
-    launch_match(c->d_mrows[0], c->d_mnorm[0], n1, c->d_mrows[1], c->d_mnorm[1], n2, ratio, d_index2, d_dist2, c->stream);
+    launch_match(c->d_mrows[0], c->d_mnorm[0], n1, c->d_mrows[1], c->d_mnorm[1], n2, ratio, d_index2, d_dist2, c->d_mpart,
+                 match_slices(n1, n2), c->stream);
     HIPCHK(c, hipGetLastError());
     return SG_OK;
 }
@@ -1143,7 +1158,7 @@ int sg_match(sg_ctx *c, const sg_keypoint *f1, size_t n1, const sg_keypoint *f2,
         if ((rc = match_prepare(c, 1, d_f, 1, n2)) != SG_OK)
             break;
         launch_match(c->d_mrows[0], c->d_mnorm[0], (unsigned int)n1, c->d_mrows[1], c->d_mnorm[1], (unsigned int)n2,
-                     ratio, d_idx, nullptr, s);
+                     ratio, d_idx, nullptr, c->d_mpart, match_slices((unsigned int)n1, (unsigned int)n2), s);
         if (hipMemcpyAsync(idx.data(), d_idx, sizeof(int) * n1, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipMemcpyAsync(&bad, c->d_mbad, sizeof bad, hipMemcpyDeviceToHost, s) != hipSuccess ||
             hipStreamSynchronize(s) != hipSuccess) {

@@ -83,6 +83,10 @@ struct sg_ctx {
     unsigned long long *d_ctr = nullptr; // [B][8]
     unsigned int *d_overflow = nullptr;  // [4]: candidates, keypoints, features, output
     void *d_out = nullptr;
+    // pinned staging for large downloads into pageable caller memory: two halves, filled and emptied alternately
+    unsigned char *h_stage = nullptr;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    bool stage_tried = false;
     size_t out_bytes = 0;
     unsigned int *d_outcounts = nullptr;
 
@@ -545,6 +549,47 @@ static int ensure_out(sg_ctx *c, size_t bytes)
     return SG_OK;
 }
 
+// Device -> pageable host memory for large results.  A plain hipMemcpy into pageable memory runs at a fraction of the
+// link's rate; here the bytes come down in 4 MB pieces into pinned memory and are copied out by the CPU while the next
+// piece is in flight.  Falls back to the plain copy when pinned memory cannot be had.  Synchronises the stream.
+constexpr size_t kStagePiece = 4u << 20;
+
+static int download_staged(sg_ctx *c, void *dst, const void *d_src, size_t bytes)
+{
+    if (!c->stage_tried) {
+        c->stage_tried = true;
+        if (hipHostMalloc((void **)&c->h_stage, 2 * kStagePiece, hipHostMallocDefault) != hipSuccess) {
+            c->h_stage = nullptr;
+            (void)hipGetLastError();
+        } else if (hipEventCreateWithFlags(&c->stage_ev[0], hipEventDisableTiming) != hipSuccess ||
+                   hipEventCreateWithFlags(&c->stage_ev[1], hipEventDisableTiming) != hipSuccess) {
+            (void)hipHostFree(c->h_stage);
+            c->h_stage = nullptr;
+            (void)hipGetLastError();
+        }
+    }
+    if (!c->h_stage || bytes < 2 * kStagePiece) {
+        HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return SG_OK;
+    }
+    const size_t pieces = (bytes + kStagePiece - 1) / kStagePiece;
+    for (size_t i = 0; i <= pieces; i++) {
+        if (i < pieces) {
+            const size_t off = i * kStagePiece, len = bytes - off < kStagePiece ? bytes - off : kStagePiece;
+            HIPCHK(c, hipMemcpyAsync(c->h_stage + (i & 1) * kStagePiece, (const char *)d_src + off, len,
+                                     hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipEventRecord(c->stage_ev[i & 1], c->stream));
+        }
+        if (i >= 1) { // piece i-1 has landed once its event has passed; its half is refilled by piece i+1, issued after this copy
+            const size_t off = (i - 1) * kStagePiece, len = bytes - off < kStagePiece ? bytes - off : kStagePiece;
+            HIPCHK(c, hipEventSynchronize(c->stage_ev[(i - 1) & 1]));
+            memcpy((char *)dst + off, c->h_stage + ((i - 1) & 1) * kStagePiece, len);
+        }
+    }
+    return SG_OK;
+}
+
 // =========================================================================================== C ABI
 
 extern "C" {
@@ -608,6 +653,11 @@ int sg_destroy(sg_ctx *c)
     for (void *b : mbufs)
         if (b)
             (void)hipFree(b);
+    if (c->h_stage)
+        (void)hipHostFree(c->h_stage);
+    for (hipEvent_t e : c->stage_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     if (c->ev.created)
         for (int i = 0; i < kEventPairs; i++) {
             (void)hipEventDestroy(c->ev.start[i]);
@@ -834,9 +884,7 @@ int sg_extract(sg_ctx *c, const uint8_t *px, int width, int height, int channels
     if (rc != SG_OK)
         return rc;
     pack_phase(c, c->d_out, nf, nf, nullptr, 1, 1, 1);
-    HIPCHK(c, hipMemcpyAsync(out, c->d_out, sizeof(sg_keypoint) * (size_t)nf, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    return SG_OK;
+    return download_staged(c, out, c->d_out, sizeof(sg_keypoint) * (size_t)nf);
 }
 
 // ---- inspection -------------------------------------------------------------------------------------------

@@ -49,6 +49,24 @@ def test_blur_reflect101_small_plane(oracle):
     assert np.allclose(oracle.gaussian_blur(row, 3.09)[0], ref, atol=1e-15)
 
 
+def test_blur_against_scipy_mirror_correlation(oracle):
+    """An independent evaluation of the documented cv::GaussianBlur semantics (taps n = cvRound(8 sigma + 1) | 1,
+    exp(-x^2 / 2 sigma^2) normalised, BORDER_REFLECT_101 = scipy's 'mirror', rows then columns): scipy.ndimage's
+    separable correlation agrees with the oracle's blur to rounding, on planes larger and smaller than the kernel."""
+    ndimage = pytest.importorskip("scipy.ndimage")
+    rng = np.random.default_rng(5)
+    for shape, sigma in (((48, 64), 1.249), ((37, 53), 3.090016), ((9, 40), 3.090016), ((30, 7), 2.452547)):
+        src = rng.random(shape)
+        n = int(np.rint(8 * sigma + 1)) | 1
+        x = np.arange(n) - (n - 1) / 2
+        k = np.exp(-(x * x) / (2 * sigma * sigma))
+        k /= k.sum()
+        assert np.allclose(oracle.gaussian_kernel(sigma), k, rtol=0, atol=1e-16)
+        want = ndimage.correlate1d(ndimage.correlate1d(src, k, axis=1, mode="mirror"), k, axis=0, mode="mirror")
+        got = oracle.gaussian_blur(src, sigma)
+        assert np.allclose(got, want, rtol=0, atol=4e-15), (shape, sigma, np.abs(got - want).max())
+
+
 def test_upsample_edges(oracle):
     src = np.arange(12, dtype=np.float64).reshape(3, 4)
     up = oracle.upsample(src)

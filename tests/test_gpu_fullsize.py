@@ -96,3 +96,64 @@ def test_8k_image_known_counts():
         assert (np.diff(f["scale"]) >= 0).all()
         assert f["x"].min() >= 0 and f["x"].max() < 7680 and f["y"].min() >= 0 and f["y"].max() < 4320
         assert f["desc"].max() <= 255 and f["desc"].any(axis=1).all()
+
+
+def test_1080p_batch256_equals_single(oracle):
+    """The configuration bench.py times: one context of 256 1080p frames (17 GB per pyramid level, image offsets
+    beyond 2^32 elements).  Every frame of the batch must come out byte-for-byte as the same frame run alone
+    (Sift() is a pure function of one frame's pixels, reference sift/sift.cpp:1646-1707); frames 0, 127 and 255
+    are also checked against the oracle.  The batch is halved while the context does not fit, as bench.py does."""
+    import sift_amd
+    W, H, cap = 1920, 1080, 26624
+    B = 256
+    big = None
+    while big is None:
+        try:
+            big = sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=B)
+        except sift_amd.SiftGpuError as e:
+            if e.status != sift_amd.api.SG_E_NOMEM or B <= 8:
+                raise
+            B //= 2
+    one = sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=1)
+    fb = W * H * 3
+    d_img = big.malloc(B * fb)
+    d_out = big.malloc(B * cap * 144)
+    d_cnt = big.malloc(B * 4)
+    d_out1 = one.malloc(cap * 144)
+    d_cnt1 = one.malloc(4)
+    try:
+        for i in range(B):
+            big.synth_vnoise5(d_img + i * fb, W, H, 1000 + i)
+        big.sync()
+        big.extract_batch_device(d_img, B, W, H, 3, d_out, cap, d_cnt)
+        big.sync()  # raises on any capacity overflow
+        counts = np.zeros(B, dtype=np.uint32)
+        big.d2h(counts, d_cnt)
+        assert counts.min() > 15000 and counts.max() < cap, (counts.min(), counts.max())
+        check = {0, B // 2 - 1, B - 1}
+        for i in range(B):
+            one.extract_batch_device(d_img + i * fb, 1, W, H, 3, d_out1, cap, d_cnt1)
+            one.sync()
+            c1 = np.zeros(1, dtype=np.uint32)
+            one.d2h(c1, d_cnt1)
+            assert int(c1[0]) == int(counts[i]), (i, int(c1[0]), int(counts[i]))
+            a = np.zeros(int(c1[0]), dtype=sift_amd.PACKED_DTYPE)
+            b = np.zeros(int(c1[0]), dtype=sift_amd.PACKED_DTYPE)
+            one.d2h(a, d_out1)
+            big.d2h(b, d_out + i * cap * 144)
+            assert a.tobytes() == b.tobytes(), "frame %d of the batch differs from the same frame run alone" % i
+            if i in check:
+                ctr_b = big.read_counters(image=i)
+                assert ctr_b == one.read_counters()
+                ref, nk, ctr, _ = oracle.sift(sift_amd.vnoise5(W, H, 1000 + i))
+                assert ctr == ctr_b, (i, ctr, ctr_b)
+                assert len(ref) == len(b)
+                assert np.array_equal(ref["descriptor"].astype(np.uint8), b["desc"]), i
+                assert np.array_equal(ref["dx"].astype(np.float32), b["x"]) and \
+                    np.array_equal(ref["dy"].astype(np.float32), b["y"])
+                assert np.allclose(ref["scale"], b["scale"], rtol=1e-6) and np.abs(ref["ori"] - b["ori"]).max() < 1e-6
+    finally:
+        for c, p in ((big, d_img), (big, d_out), (big, d_cnt), (one, d_out1), (one, d_cnt1)):
+            c.free(p)
+        big.close()
+        one.close()

@@ -216,6 +216,18 @@ int sg_match(sg_ctx *ctx, const sg_keypoint *f1, size_t n1, const sg_keypoint *f
 int sg_match_packed_device(sg_ctx *ctx, const sg_packed_feature *d_f1, uint32_t n1, const sg_packed_feature *d_f2,
                            uint32_t n2, double ratio, int32_t *d_index2, uint32_t *d_dist2);
 
+/* Allocation-free form of sg_match_packed_device: same arguments, same results, but no hipMalloc/hipFree and no
+ * allocating library call anywhere in it.  It has no counterpart in the reference; it exists for callers that
+ * cannot allocate: code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Its scratch
+ * (signed-byte rows, norms and per-slice partial results, 14.7 MB) is a static device array that every GPU the
+ * library runs on holds until the process ends, so the sets are limited to SG_MATCH_NOALLOC_MAX features each
+ * (SG_E_CAPACITY beyond that).  All calls on one GPU share that array: calls that overlap on one GPU (two
+ * streams, two contexts, two threads) race; serialise them.  Asynchronous on the context's stream. */
+#define SG_MATCH_NOALLOC_MAX 32768
+int sg_match_packed_device_noalloc(sg_ctx *ctx, const sg_packed_feature *d_f1, uint32_t n1,
+                                   const sg_packed_feature *d_f2, uint32_t n2, double ratio, int32_t *d_index2,
+                                   uint32_t *d_dist2);
+
 /* ---- device memory and synthetic input (so that callers need no HIP binding of their own) ---- */
 
 int sg_malloc(sg_ctx *ctx, size_t bytes, void **d_ptr);

@@ -39,6 +39,7 @@ EXPORTS = (
     "sg_level_dims", "sg_read_level", "sg_read_counters", "sg_read_keypoints", "sg_read_features_unsorted",
     "sg_set_profiling", "sg_get_stage_times", "sg_reset_stage_times", "sg_malloc", "sg_free", "sg_memcpy_h2d",
     "sg_memcpy_d2h", "sg_synth_vnoise5", "sg_match", "sg_match_packed_device",
+    "sg_match_packed_device_noalloc",
 )
 
 
@@ -108,6 +109,7 @@ def load_library():
     L.sg_sort_features.argtypes = [vp, vp, C.c_size_t]
     L.sg_match.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_double, vp, C.c_size_t, szp]
     L.sg_match_packed_device.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_double, vp, vp]
+    L.sg_match_packed_device_noalloc.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_double, vp, vp]
     L.sg_last_octaves.argtypes = [vp]
     L.sg_level_dims.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.sg_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
@@ -362,6 +364,10 @@ class SiftGPU:
     def match_packed_device(self, d_f1, n1, d_f2, n2, d_index2, d_dist2=None, ratio=0.5):
         """Device-pointer form on packed features (ints); asynchronous. d_index2: n1 int32; d_dist2: 2*n1 uint32 or None."""
         self._check(self.lib.sg_match_packed_device(self.ctx, d_f1, n1, d_f2, n2, ratio, d_index2, d_dist2))
+
+    def match_packed_device_noalloc(self, d_f1, n1, d_f2, n2, d_index2, d_dist2=None, ratio=0.5):
+        """match_packed_device without any device allocation (static scratch; at most 32768 features per set)."""
+        self._check(self.lib.sg_match_packed_device_noalloc(self.ctx, d_f1, n1, d_f2, n2, ratio, d_index2, d_dist2))
 
     # ---- inspection ------------------------------------------------------------------------------------
     def last_octaves(self):

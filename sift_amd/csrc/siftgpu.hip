@@ -12,6 +12,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -25,6 +26,44 @@ static_assert(sizeof(KpRec) == 80, "KpRec is 80 bytes");
 static_assert(sizeof(FeatRec) == 64, "FeatRec is 64 bytes");
 
 namespace {
+
+// ---- scratch of the allocation-free matcher (sg_match_packed_device_noalloc) ---------------------------------
+// One array per GPU, held from the moment the library's code object is loaded on that GPU until the process
+// ends.  Layout: signed-byte rows of the two feature sets, their squared norms, the per-slice partial results,
+// one flag word.  Host code never uses the array's name as an address: its device address is resolved once per
+// device by static_scratch_for() and kept.
+constexpr unsigned int kStaticMatchMax = 32768; // features per set
+constexpr size_t kSsRows = (size_t)kStaticMatchMax * 128;
+constexpr size_t kSsNorms = (size_t)kStaticMatchMax * sizeof(int);
+constexpr size_t kSsPart = (size_t)kStaticMatchMax * kMatchMaxSlices * 12;
+constexpr size_t kSsOffRows0 = 0, kSsOffRows1 = kSsRows, kSsOffNorm0 = 2 * kSsRows, kSsOffNorm1 = kSsOffNorm0 + kSsNorms,
+                 kSsOffPart = kSsOffNorm1 + kSsNorms, kSsOffBad = kSsOffPart + kSsPart, kSsBytes = kSsOffBad + 256;
+static_assert(kSsOffNorm0 % 256 == 0 && kSsOffNorm1 % 256 == 0 && kSsOffPart % 256 == 0 && kSsOffBad % 256 == 0,
+              "every part starts on a 256-byte boundary");
+static __device__ __align__(256) unsigned char scratch[kSsBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+unsigned char *g_scratch_ptr[kMaxDevices]; // device address of `scratch` on each GPU, resolved on first use
+
+// Device address of this GPU's copy of `scratch`; `device` must be the current device.  nullptr on failure.
+unsigned char *static_scratch_for(int device, hipError_t *err)
+{
+    *err = hipSuccess;
+    if (device < 0 || device >= kMaxDevices) {
+        *err = hipErrorInvalidDevice;
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void *p = nullptr;
+        *err = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (*err != hipSuccess)
+            return nullptr;
+        g_scratch_ptr[device] = static_cast<unsigned char *>(p);
+    }
+    return g_scratch_ptr[device];
+}
 
 constexpr int kEventPairs = 4096;
 
@@ -51,6 +90,7 @@ struct sg_ctx {
     unsigned int *d_mbad = nullptr;
     void *d_mpart = nullptr; // per-slice partial results of the matcher
     size_t mpart_bytes = 0;
+    unsigned char *static_scratch = nullptr; // this device's copy of the allocation-free matcher's scratch array
 
     // geometry of the current call
     int w = 0, h = 0, octaves = 0, last_batch = 0;
@@ -754,6 +794,15 @@ int sg_create(const sg_params *p, sg_ctx **out)
         delete c;
         return SG_E_HIP;
     }
+    {
+        hipError_t e = hipSuccess;
+        c->static_scratch = static_scratch_for(p->device, &e); // p->device is current (hipSetDevice above)
+        if (!c->static_scratch) {
+            (void)hipStreamDestroy(c->stream);
+            delete c;
+            return SG_E_HIP;
+        }
+    }
     ALLOC(c->d_up, c->esize * c->plane0_elems * B);
     ALLOC(c->d_tmp, c->esize * c->plane0_elems * B);
     ALLOC(c->d_levels, c->esize * c->levels_elems);
@@ -1165,6 +1214,30 @@ int sg_match_packed_device(sg_ctx *c, const sg_packed_feature *d_f1, uint32_t n1
     if (rc != SG_OK)
         return rc;
     launch_match(c->d_mrows[0], c->d_mnorm[0], n1, c->d_mrows[1], c->d_mnorm[1], n2, ratio, d_index2, d_dist2, c->d_mpart,
+                 match_slices(n1, n2), c->stream);
+    HIPCHK(c, hipGetLastError());
+    return SG_OK;
+}
+
+int sg_match_packed_device_noalloc(sg_ctx *c, const sg_packed_feature *d_f1, uint32_t n1,
+                                   const sg_packed_feature *d_f2, uint32_t n2, double ratio, int32_t *d_index2,
+                                   uint32_t *d_dist2)
+{
+    if (!c || (n1 && (!d_f1 || !d_index2)) || (n2 && !d_f2))
+        return SG_E_INVALID;
+    if (n1 > kStaticMatchMax || n2 > kStaticMatchMax)
+        return fail(c, SG_E_CAPACITY, "sg_match_packed_device_noalloc takes at most 32768 features per set");
+    (void)hipSetDevice(c->prm.device);
+    unsigned char *sp = c->static_scratch; // resolved by sg_create on this device
+    signed char *rows[2] = {(signed char *)(sp + kSsOffRows0), (signed char *)(sp + kSsOffRows1)};
+    int *norms[2] = {(int *)(sp + kSsOffNorm0), (int *)(sp + kSsOffNorm1)};
+    unsigned int *bad = (unsigned int *)(sp + kSsOffBad);
+    // The array keeps the previous call's contents.  Rows and norms 0 .. n_pad-1 of both sets and the partial results
+    // of features 0 .. n1-1 are rewritten by this call before they are read; only the flag word must start at zero.
+    HIPCHK(c, hipMemsetAsync(bad, 0, sizeof(unsigned int), c->stream));
+    launch_match_prep(d_f1, 0, n1, match_pad(n1), rows[0], norms[0], bad, c->stream);
+    launch_match_prep(d_f2, 0, n2, match_pad(n2), rows[1], norms[1], bad, c->stream);
+    launch_match(rows[0], norms[0], n1, rows[1], norms[1], n2, ratio, d_index2, d_dist2, sp + kSsOffPart,
                  match_slices(n1, n2), c->stream);
     HIPCHK(c, hipGetLastError());
     return SG_OK;

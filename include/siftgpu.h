@@ -99,6 +99,11 @@ int sg_device_count(void);
 int sg_create(const sg_params *p, sg_ctx **out);
 int sg_destroy(sg_ctx *ctx);
 int sg_sync(sg_ctx *ctx);
+/* After a call has returned SG_E_CAPACITY for an internal buffer (3x3x3 extrema, keypoints or features of one image
+ * exceeded what sg_params.max_features sized): the max_features a new context needs for that image.  The default
+ * (max_features = 0) sizes for width*height/40 + 4096 features per image, about four times the density of natural
+ * texture; the reference has no such limit, so its host mirror recreates the context and runs again. */
+int sg_required_features(const sg_ctx *ctx, size_t *max_features);
 
 /* ---- whole path ---------------------------------------------------------------------------- */
 
@@ -107,6 +112,13 @@ int sg_sync(sg_ctx *ctx);
  * by ascending scale, exact ties in emission order (octave, interval, y, x, orientation bin). */
 int sg_extract(sg_ctx *ctx, const uint8_t *px, int width, int height, int channels, size_t stride,
                sg_keypoint *out, size_t cap, size_t *n);
+
+/* The same call in two steps, for callers that size their output from the count (the host mirror of Sift() appends
+ * to a std::vector): sg_extract_begin runs the path and returns the number of features; sg_extract_fetch then writes
+ * those records (it may be called more than once until the next sg_extract_begin).  sg_extract is one after the
+ * other.  An internal-capacity overflow is reported by sg_extract_begin (SG_E_CAPACITY, see sg_required_features). */
+int sg_extract_begin(sg_ctx *ctx, const uint8_t *px, int width, int height, int channels, size_t stride, size_t *n);
+int sg_extract_fetch(sg_ctx *ctx, sg_keypoint *out, size_t cap, size_t *n);
 
 /* Throughput form of the same path: n_img device-resident images of one size (image i starts at
  * d_imgs + i*img_stride), packed features written to d_out + i*cap_per_image, counts to d_counts[i].

@@ -31,8 +31,8 @@ assert PACKED_DTYPE.itemsize == 144
 
 # Every symbol include/siftgpu.h declares.
 EXPORTS = (
-    "sg_default_params", "sg_strerror", "sg_last_error", "sg_device_count", "sg_create", "sg_destroy", "sg_sync",
-    "sg_extract", "sg_extract_batch_device", "sg_extract_batch", "sg_convert_to_gray", "sg_upsample",
+    "sg_default_params", "sg_strerror", "sg_last_error", "sg_device_count", "sg_create", "sg_destroy", "sg_sync", "sg_required_features",
+    "sg_extract", "sg_extract_begin", "sg_extract_fetch", "sg_extract_batch_device", "sg_extract_batch", "sg_convert_to_gray", "sg_upsample",
     "sg_downsample", "sg_gaussian_smooth", "sg_create_init_smooth_gray", "sg_gaussian_pyramid", "sg_sub",
     "sg_dog_pyramid", "sg_detect_local_extrema", "sg_calculate_scale", "sg_half_features",
     "sg_orientation_assignment", "sg_descriptor_representation", "sg_sort_features", "sg_last_octaves",
@@ -87,7 +87,10 @@ def load_library():
     L.sg_create.argtypes = [C.POINTER(Params), C.POINTER(vp)]
     L.sg_destroy.argtypes = [vp]
     L.sg_sync.argtypes = [vp]
+    L.sg_required_features.argtypes = [vp, szp]
     L.sg_extract.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, szp]
+    L.sg_extract_begin.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_size_t, szp]
+    L.sg_extract_fetch.argtypes = [vp, vp, C.c_size_t, szp]
     L.sg_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp,
                                           C.c_size_t, vp]
     L.sg_extract_batch.argtypes = [vp, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp,
@@ -217,6 +220,12 @@ class SiftGPU:
 
     def sync(self):
         self._check(self.lib.sg_sync(self.ctx))
+
+    def required_features(self):
+        """max_features a new context needs after an internal-capacity overflow was reported."""
+        n = C.c_size_t(0)
+        self._check(self.lib.sg_required_features(self.ctx, C.byref(n)))
+        return n.value
 
     # ---- device memory helpers ---------------------------------------------------------------
     def malloc(self, nbytes):

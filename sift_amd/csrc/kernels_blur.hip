@@ -951,7 +951,7 @@ void blur_dma_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
 template <typename T, int V>
 static bool blur_dma_ok(const Plane &src)
 {
-    if (getenv("SIFTGPU_BLUR_DIRECT"))
+    if (env().blur_direct)
         return false;
     return (uintptr_t)src.p % 16 == 0 && src.pitch % V == 0 && src.pitch >= V &&
            (src.img_stride * sizeof(T)) % 16 == 0 && (size_t)src.pitch * sizeof(T) < (1ull << 31);
@@ -1042,7 +1042,7 @@ static T *upload_taps(const double *taps, int n, hipStream_t s)
 }
 
 template <typename T, int V, int U>
-static void row_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s,
+static bool row_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s,
                          const void *d_taps)
 {
     const int rows = src.rows, cols = src.cols;
@@ -1050,7 +1050,7 @@ static void row_dispatch(const Plane &src, const Plane &dst, int B, const double
     if (n <= 1 || cols == 1) { // a 1-pixel dimension shrinks the kernel to one tap
         copy_plane_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride,
                                            dst.img_stride);
-        return;
+        return true;
     }
     int R = bucket_radius(n / 2);
     constexpr int TW = 64 * V * U;
@@ -1072,6 +1072,8 @@ static void row_dispatch(const Plane &src, const Plane &dst, int B, const double
                                                  src.img_stride, dst.img_stride, (const T *)d_taps, n);
         } else {
             T *dt = upload_taps<T>(taps, n, s);
+            if (!dt)
+                return false; // no device memory for the taps (or more taps than the any-radius kernels take)
             blur_row_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
                                                  src.img_stride, dst.img_stride, dt, n);
             hipStreamSynchronize(s);
@@ -1080,10 +1082,11 @@ static void row_dispatch(const Plane &src, const Plane &dst, int B, const double
     }
     }
 #undef SG_ROW_CASE
+    return true;
 }
 
 template <typename T, int V, int RPT>
-static void col_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s,
+static bool col_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s,
                          const void *d_taps)
 {
     const int rows = src.rows, cols = src.cols;
@@ -1091,7 +1094,7 @@ static void col_dispatch(const Plane &src, const Plane &dst, int B, const double
     if (n <= 1 || rows == 1) {
         copy_plane_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride,
                                            dst.img_stride);
-        return;
+        return true;
     }
     int R = bucket_radius(n / 2);
     constexpr int TW = 64 * V, TH = 4 * RPT;
@@ -1114,6 +1117,8 @@ static void col_dispatch(const Plane &src, const Plane &dst, int B, const double
                                                  src.img_stride, dst.img_stride, (const T *)d_taps, n);
         } else {
             T *dt = upload_taps<T>(taps, n, s);
+            if (!dt)
+                return false; // no device memory for the taps (or more taps than the any-radius kernels take)
             blur_col_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
                                                  src.img_stride, dst.img_stride, dt, n);
             hipStreamSynchronize(s);
@@ -1122,6 +1127,7 @@ static void col_dispatch(const Plane &src, const Plane &dst, int B, const double
     }
     }
 #undef SG_COL_CASE
+    return true;
 }
 
 bool blur_fused_supported(const Plane &src, int n)
@@ -1140,13 +1146,7 @@ bool blur_fused_supported(const Plane &src, int n)
 // and row-filtered again) dominate.  per_row = strips x frames.
 static int win_segment_rows(int rows, long long per_row, int R, int waves_per_simd)
 {
-    static const int n_cu = [] {
-        int dev = 0, cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
-            cu = 256;
-        return cu;
-    }();
+    const int n_cu = env().n_cu;
     const long long slots = (long long)n_cu * 4 * waves_per_simd * 2;
     int nseg_want = (int)(slots / per_row);
     if (nseg_want < 1)
@@ -1163,13 +1163,9 @@ static int win_segment_rows(int rows, long long per_row, int R, int waves_per_si
 // register-window variant is the default for every radius.
 static bool blur_use_ring(int R, size_t elem)
 {
-    static const bool ring = [] {
-        const char *e = getenv("SIFTGPU_BLUR");
-        return e && strcmp(e, "ring") == 0;
-    }();
     (void)R;
     (void)elem;
-    return ring;
+    return env().blur_mode == 2;
 }
 
 template <typename T, int V>
@@ -1262,7 +1258,7 @@ static bool ups_dispatch(const Plane &gray, const Plane &dst, int B, const doubl
     const int nseg = (rows + seg - 1) / seg;
     dim3 g((strips + 3) / 4, nseg, B);
     // gray rows staged by direct-to-LDS loads when they are 16-byte aligned (SIFTGPU_BLUR_DIRECT=1: loaded by the lanes)
-    const bool gdma = !getenv("SIFTGPU_BLUR_DIRECT") && (uintptr_t)gray.p % 16 == 0 && gray.pitch % 2 == 0 &&
+    const bool gdma = !env().blur_direct && (uintptr_t)gray.p % 16 == 0 && gray.pitch % 2 == 0 &&
                       gray.pitch >= 2 && (gray.img_stride * sizeof(double)) % 16 == 0;
     if (gdma)
         blur_win_k<T, R, V, true, true>
@@ -1279,8 +1275,7 @@ static bool ups_dispatch(const Plane &gray, const Plane &dst, int B, const doubl
 bool launch_blur_fused_upsampled(const Plane &gray, const Plane &dst, int B, const double *taps, int n, int prec,
                                  hipStream_t s)
 {
-    const char *e = getenv("SIFTGPU_BLUR");
-    if (e && *e && strcmp(e, "win") != 0)
+    if (env().blur_mode == 1 || env().blur_mode == 2)
         return false; // another variant is forced
     if (prec == SG_F64)
         return ups_dispatch<double, 2>(gray, dst, B, taps, n, s);
@@ -1301,22 +1296,20 @@ bool blur_fused_decimates(const Plane &src, int n, int prec)
            !blur_use_ring(bucket_radius(n / 2), prec == SG_F64 ? 8 : 4);
 }
 
-void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+bool launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
                      const void *d_taps)
 {
     if (prec == SG_F64)
-        row_dispatch<double, 2, 2>(src, dst, B, taps, n, s, d_taps);
-    else
-        row_dispatch<float, 4, 1>(src, dst, B, taps, n, s, d_taps);
+        return row_dispatch<double, 2, 2>(src, dst, B, taps, n, s, d_taps);
+    return row_dispatch<float, 4, 1>(src, dst, B, taps, n, s, d_taps);
 }
 
-void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+bool launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
                      const void *d_taps)
 {
     if (prec == SG_F64)
-        col_dispatch<double, 2, 8>(src, dst, B, taps, n, s, d_taps);
-    else
-        col_dispatch<float, 4, 8>(src, dst, B, taps, n, s, d_taps);
+        return col_dispatch<double, 2, 8>(src, dst, B, taps, n, s, d_taps);
+    return col_dispatch<float, 4, 8>(src, dst, B, taps, n, s, d_taps);
 }
 
 } // namespace sg

@@ -231,20 +231,13 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
 // a wave that takes several entries can load the next record while it works on the current one, so a launch holds a
 // fixed number of waves in all -- waves_per_cu for every compute unit, a few rounds of the resident waves, enough to
 // even out the differences between windows -- and at least min_per_image per image, whatever the list lengths.  (With one wave per entry the orientation
-// kernel ran 30 % longer.)  The environment variable overrides the total, for experiments.
+// kernel ran 30 % longer.)  SIFTGPU_ORI_WAVES / SIFTGPU_DESCR_WAVES (read once per process) override the total, for experiments.
 static unsigned int feature_blocks(unsigned int cap, int B, unsigned int waves_per_cu, unsigned int min_per_image,
-                                   const char *env)
+                                   int total_override)
 {
-    static const unsigned int n_cu = [] {
-        int dev = 0, cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cu <= 0)
-            cu = 256;
-        return (unsigned int)cu;
-    }();
-    unsigned int total = n_cu * waves_per_cu;
-    if (const char *e = getenv(env))
-        total = (unsigned int)atoi(e);
+    unsigned int total = (unsigned int)env().n_cu * waves_per_cu;
+    if (total_override > 0)
+        total = (unsigned int)total_override;
     unsigned int blocks = total / (unsigned int)(B > 0 ? B : 1);
     if (blocks < min_per_image) // large batches: a wave still takes no more than a few dozen entries of an image
         blocks = min_per_image;
@@ -256,7 +249,7 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
                    unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
                    size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec, hipStream_t s)
 {
-    unsigned int blocks = feature_blocks(cap, B, 64, 256, "SIFTGPU_ORI_WAVES");
+    unsigned int blocks = feature_blocks(cap, B, 64, 256, env().ori_waves);
     if (blocks == 0)
         return;
     dim3 g(blocks, B);
@@ -580,7 +573,7 @@ void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_str
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
                   int max_radius, int B, int prec, hipStream_t s)
 {
-    unsigned int blocks = feature_blocks(cap, B, 384, 384, "SIFTGPU_DESCR_WAVES");
+    unsigned int blocks = feature_blocks(cap, B, 384, 384, env().descr_waves);
     if (blocks == 0)
         return;
     dim3 g(blocks, B);
@@ -746,6 +739,30 @@ __global__ __launch_bounds__(256) void pack_k(const KpRec *kp, size_t kp_img, co
         if (n > out_cap)
             atomicMax(overflow, n);
     }
+    if (MODE == 3) {
+        // as MODE 0, with the full-precision header: lanes 0..7 copy the descriptor, lane 8 writes the 96 header bytes
+        const int sub = threadIdx.x & 15;
+        for (unsigned int f = blockIdx.x * 16u + (threadIdx.x >> 4); f < n; f += gridDim.x * 16u) {
+            const unsigned int pos = sorted ? rank[(size_t)b * rank_img + f] : f;
+            if (pos >= out_cap)
+                continue;
+            WireRec *o = reinterpret_cast<WireRec *>(out) + (size_t)b * out_img + pos;
+            if (sub < 8) {
+                const uint4 v = reinterpret_cast<const uint4 *>(desc + (size_t)b * desc_img + (size_t)f * 128)[sub];
+                reinterpret_cast<uint4 *>(o->desc)[sub] = v;
+            } else if (sub == 8) {
+                const unsigned int fs = feat_src[(size_t)b * fsrc_img + f];
+                const unsigned int j = fs >> 6, pbin = fs & 63;
+                const KpRec *r = kp + (size_t)b * kp_img + kp_src[(size_t)b * src_img + j];
+                o->octave = r->octave; o->interval = r->interval; o->x = r->x; o->y = r->y;
+                o->offi = r->offi; o->scale = r->scale; o->dx = r->dx; o->dy = r->dy;
+                o->offx = r->offx; o->offy = r->offy; o->oscale = r->oscale;
+                o->ori = ori_tmp[(size_t)b * ori_img + (size_t)j * kOriBins + pbin];
+                o->val = r->val; o->pad = 0.0;
+            }
+        }
+        return;
+    }
     if (MODE == 0) {
         // 16 lanes per feature, so that a wave follows four index chains at a time: lanes 0..7 of a group copy the
         // descriptor in 16-byte pieces, lane 8 writes the 16-byte header
@@ -810,13 +827,17 @@ void launch_pack(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_s
                  unsigned int out_cap, unsigned int *out_counts, unsigned int *overflow, int mode, int sorted,
                  unsigned int cap, int B, hipStream_t s)
 {
-    unsigned int blocks = mode == 0 ? (cap + 15) / 16 : (cap + 3) / 4;
+    unsigned int blocks = (mode == 0 || mode == 3) ? (cap + 15) / 16 : (cap + 3) / 4;
     if (blocks > 2048)
         blocks = 2048;
     if (blocks == 0)
         blocks = 1;
     dim3 g(blocks, B);
-    if (mode == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)desc % 16 == 0 && desc_img_stride % 16 == 0)
+    if (mode == 3)
+        pack_k<3><<<g, 256, 0, s>>>(kp, kp_img_stride, kp_src, src_img_stride, feat_src, fsrc_img_stride, feat_count,
+                                    ori_tmp, ori_img_stride, desc, desc_img_stride, rank, rank_img_stride, out,
+                                    out_img_stride, out_cap, out_counts, overflow, sorted, cap);
+    else if (mode == 0 && (uintptr_t)out % 16 == 0 && (uintptr_t)desc % 16 == 0 && desc_img_stride % 16 == 0)
         pack_k<0><<<g, 256, 0, s>>>(kp, kp_img_stride, kp_src, src_img_stride, feat_src, fsrc_img_stride, feat_count,
                                     ori_tmp, ori_img_stride, desc, desc_img_stride, rank, rank_img_stride, out,
                                     out_img_stride, out_cap, out_counts, overflow, sorted, cap);

@@ -422,7 +422,7 @@ static bool detect_staged_ok(const OctaveTab &tab, int o, int prec)
 {
     const size_t esz = prec == SG_F64 ? 8 : 4;
     const int nl = tab.from_dog ? kDogLevels : kLevels;
-    if (getenv("SIFTGPU_DETECT_DIRECT"))
+    if (env().detect_direct)
         return false;
     if ((size_t)tab.pitch[o] * esz % 16 || (size_t)tab.img_stride[o] * esz % 16)
         return false;

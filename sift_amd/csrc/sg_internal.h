@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "siftgpu.h"
@@ -18,6 +19,19 @@ constexpr int kBorder = 5;        // IMG_BORDER, sift.h:58
 constexpr int kChunkWords = 1024; // bitmap words per compaction chunk
 constexpr int kOriBins = 36;
 constexpr int kRankBuckets = 16384; // 16 binades x 1024 mantissa steps of the scale key
+
+// Debug / comparison switches, read from the environment once per process (first sg_create) and never on a launch path:
+//   SIFTGPU_BLUR=2pass|ring|win   blur variant (default: the register-window kernels with LDS-DMA staging)
+//   SIFTGPU_BLUR_DIRECT=1         input rows loaded by the lanes instead of LDS-DMA
+//   SIFTGPU_DETECT_DIRECT=1       detect rows loaded into registers instead of LDS-DMA
+//   SIFTGPU_ORI_WAVES / SIFTGPU_DESCR_WAVES   total waves of the orientation / descriptor launches
+struct Env {
+    int blur_mode = 0; // 0 default, 1 "2pass", 2 "ring", 3 "win"
+    bool blur_direct = false, detect_direct = false;
+    int ori_waves = 0, descr_waves = 0; // 0 = library default
+    int n_cu = 256;                     // compute units of the current device at first use
+};
+const Env &env();
 
 // One image plane (or a batch of them): element pointer, geometry in elements.
 struct Plane {
@@ -60,6 +74,16 @@ struct FeatRec {
     unsigned int kp_slot, pad;
 };
 
+// A feature as it crosses the bus towards sg_keypoint records on the host: every field of the record, with the
+// descriptor as the 128 bytes it is rather than 128 doubles (224 bytes instead of 1120); expanded by the CPU.
+struct WireRec {
+    int octave, interval, x, y;
+    double offi, scale, dx, dy, offx, offy, oscale, ori, val;
+    double pad;
+    uint8_t desc[128];
+};
+static_assert(sizeof(WireRec) == 224 && offsetof(WireRec, desc) == 96, "16-byte pieces");
+
 // ---- image preparation -----------------------------------------------------------------
 void launch_gray(const uint8_t *src, int rows, int cols, int ch, size_t stride, size_t img_stride,
                  const Plane &dst, int B, int prec, hipStream_t s);
@@ -73,10 +97,10 @@ void launch_vnoise5(uint8_t *dst, int rows, int cols, uint64_t seed, hipStream_t
 // ---- blur ---------------------------------------------------------------------------------
 // taps: n doubles (host), n odd. Row pass src->tmp, column pass tmp->dst. In-place (src==dst) is allowed.
 // d_taps (optional): the n taps already on the device in the plane's type; without it a blur wider than the unrolled
-// kernels uploads them itself (allocating and synchronising)
-void launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+// kernels uploads them itself (allocating and synchronising); false (nothing launched) when that upload fails
+bool launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
                      const void *d_taps = nullptr);
-void launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
+bool launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
                      const void *d_taps = nullptr);
 // Row and column pass in one launch (src != dst). Returns false, launching nothing, where only the two-pass
 // kernels apply (1-pixel-wide or -high planes, radius beyond the fast kernels).
@@ -127,7 +151,8 @@ void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_str
 void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
                  size_t rank_img_stride, unsigned int *bwork, unsigned int *blist, unsigned int *scratch_totals,
                  unsigned int *overflow_dummy, unsigned int cap, int B, hipStream_t s);
-// mode 0: packed features (sg_packed_feature) at out + b*out_img_stride*144; mode 1: sg_keypoint records.
+// mode 0: packed features (sg_packed_feature) at out + b*out_img_stride*144; mode 1: sg_keypoint records;
+// mode 3: WireRec records (out 16-byte aligned).
 void launch_pack(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src, size_t src_img_stride,
                  const unsigned int *feat_src, size_t fsrc_img_stride, const unsigned int *feat_count,
                  const double *ori_tmp, size_t ori_img_stride, const uint8_t *desc, size_t desc_img_stride,

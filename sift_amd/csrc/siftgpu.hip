@@ -7,6 +7,7 @@
 // Everything is enqueued on the context's stream with fixed grids and device-side counts, so the host
 // never waits inside a batch.
 #include <math.h>
+#include <cmath>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -19,6 +20,29 @@
 #include "sg_internal.h"
 
 using namespace sg;
+
+namespace sg {
+const Env &env()
+{
+    static const Env e = [] {
+        Env v;
+        if (const char *b = getenv("SIFTGPU_BLUR"))
+            v.blur_mode = strcmp(b, "2pass") == 0 ? 1 : strcmp(b, "ring") == 0 ? 2 : strcmp(b, "win") == 0 ? 3 : 0;
+        v.blur_direct = getenv("SIFTGPU_BLUR_DIRECT") != nullptr;
+        v.detect_direct = getenv("SIFTGPU_DETECT_DIRECT") != nullptr;
+        if (const char *w = getenv("SIFTGPU_ORI_WAVES"))
+            v.ori_waves = atoi(w);
+        if (const char *w = getenv("SIFTGPU_DESCR_WAVES"))
+            v.descr_waves = atoi(w);
+        int dev = 0, cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cu > 0)
+            v.n_cu = cu;
+        return v;
+    }();
+    return e;
+}
+} // namespace sg
 
 static_assert(sizeof(sg_keypoint) == 1120, "sg_keypoint must match the reference's Keypoint layout");
 static_assert(sizeof(sg_packed_feature) == 144, "packed feature is 144 bytes");
@@ -121,16 +145,19 @@ struct sg_ctx {
     uint8_t *d_desc = nullptr;
     unsigned int *d_counts = nullptr; // [3][B]: candidates, keypoints, features
     unsigned long long *d_ctr = nullptr; // [B][8]
-    unsigned int *d_overflow = nullptr;  // [4]: candidates, keypoints, features, output
+    unsigned int *d_overflow = nullptr;  // [4]: candidates, keypoints, features, output; sticky until read
+    unsigned int last_ov[4] = {0, 0, 0, 0}; // the counts of the last reported overflow (sg_required_features)
     void *d_out = nullptr;
     // pinned staging for large downloads into pageable caller memory: two halves, filled and emptied alternately
     unsigned char *h_stage = nullptr;
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
-    bool stage_tried = false;
+    size_t pending_features = 0; // feature count of the last sg_extract_begin, not fetched yet
+    bool have_pending = false;
     size_t out_bytes = 0;
     unsigned int *d_outcounts = nullptr;
 
     bool prof = false;
+    bool launch_failed = false; // a blur could not be launched (its taps found no device memory)
     bool fused_blur = true; // one-launch blur; SIFTGPU_BLUR=2pass selects the separate row/column kernels
     StageEvents ev;
     double stage_ms[SG_ST_COUNT];
@@ -154,6 +181,12 @@ static int fail(sg_ctx *ctx, int code, const char *msg)
     if (ctx)
         ctx->err = msg;
     return code;
+}
+
+// Bytes of a host image that are guaranteed to exist: whole strides for all rows but the last, pixels only for the last.
+static size_t image_bytes(int width, int height, int channels, size_t stride)
+{
+    return (size_t)(height - 1) * stride + (size_t)width * channels;
 }
 
 static int round_half_even(double v) { return (int)lrint(v); }
@@ -464,11 +497,13 @@ static bool blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, co
     const void *d_taps = taps == c->taps[slot] ? c->d_taps[slot] : nullptr; // the context's own levels only
     {
         StageScope sc(c, SG_ST_BLUR_ROW0 + slot);
-        launch_blur_row(src, tmp, B, taps, n, c->prm.precision, c->stream, d_taps);
+        if (!launch_blur_row(src, tmp, B, taps, n, c->prm.precision, c->stream, d_taps))
+            c->launch_failed = true;
     }
     {
         StageScope sc(c, (c->fused_blur ? SG_ST_BLUR_ROW0 : SG_ST_BLUR_COL0) + slot);
-        launch_blur_col(tmp, dst, B, taps, n, c->prm.precision, c->stream, d_taps);
+        if (!launch_blur_col(tmp, dst, B, taps, n, c->prm.precision, c->stream, d_taps))
+            c->launch_failed = true;
     }
     return false;
 }
@@ -482,7 +517,9 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
         return fail(c, SG_E_INVALID, "input needs at least 3 interleaved channels (b,g,r)");
     hipStream_t s = c->stream;
     const int prec = c->prm.precision;
-    (void)hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int) * 4, s);
+    c->launch_failed = false;
+    // d_overflow is not cleared here: the words are sticky until check_overflow has read them, so that a second batch
+    // enqueued before sg_sync cannot erase the first one's report
     if (c->octaves == 0) {
         (void)hipMemsetAsync(c->d_counts, 0, sizeof(unsigned int) * 3 * c->B, s);
         (void)hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long) * 8 * c->B, s);
@@ -539,6 +576,8 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
                 have_base = true;
         }
     }
+    if (c->launch_failed)
+        return fail(c, SG_E_NOMEM, "out of device memory (blur taps)");
     detect_phase(c, c->tab, c->n_words, B, c->prm.nointerval);
     orient_phase(c, c->tab, B, ori_max_radius(c->prm));
     descr_phase(c, c->tab, B, descr_max_radius(c->prm));
@@ -553,6 +592,9 @@ static int check_overflow(sg_ctx *c)
     HIPCHK(c, hipMemcpyAsync(ov, c->d_overflow, sizeof ov, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (ov[0] || ov[1] || ov[2] || ov[3]) {
+        memcpy(c->last_ov, ov, sizeof ov);
+        // read and reported: cleared for the calls that follow (stream order puts this after everything enqueued so far)
+        (void)hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int) * 4, c->stream);
         char buf[256];
         snprintf(buf, sizeof buf,
                  "capacity exceeded: candidates %u (cap %u), keypoints %u, features %u (cap %u), output %u",
@@ -589,42 +631,59 @@ static int ensure_out(sg_ctx *c, size_t bytes)
     return SG_OK;
 }
 
-// Device -> pageable host memory for large results.  A plain hipMemcpy into pageable memory runs at a fraction of the
-// link's rate; here the bytes come down in 4 MB pieces into pinned memory and are copied out by the CPU while the next
-// piece is in flight.  Falls back to the plain copy when pinned memory cannot be had.  Synchronises the stream.
+// Feature records for the host: the device packs WireRec records (224 bytes each), they come down in pieces into
+// pinned memory, two pieces in flight alternately, and the CPU expands each landed piece into the caller's 1120-byte
+// sg_keypoint records while the next one is on the bus.  (The record's 128 descriptor doubles hold integers 0..255:
+// moving them as bytes cuts the transfer five-fold, and the caller's memory, usually pageable, is written once, by
+// the CPU.)  Synchronises the stream.
 constexpr size_t kStagePiece = 4u << 20;
+constexpr size_t kStageRecs = kStagePiece / sizeof(WireRec);
 
-static int download_staged(sg_ctx *c, void *dst, const void *d_src, size_t bytes)
+static int ensure_stage(sg_ctx *c)
 {
-    if (!c->stage_tried) {
-        c->stage_tried = true;
-        if (hipHostMalloc((void **)&c->h_stage, 2 * kStagePiece, hipHostMallocDefault) != hipSuccess) {
-            c->h_stage = nullptr;
-            (void)hipGetLastError();
-        } else if (hipEventCreateWithFlags(&c->stage_ev[0], hipEventDisableTiming) != hipSuccess ||
-                   hipEventCreateWithFlags(&c->stage_ev[1], hipEventDisableTiming) != hipSuccess) {
-            (void)hipHostFree(c->h_stage);
-            c->h_stage = nullptr;
-            (void)hipGetLastError();
-        }
-    }
-    if (!c->h_stage || bytes < 2 * kStagePiece) {
-        HIPCHK(c, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->h_stage)
         return SG_OK;
+    HIPCHK(c, hipHostMalloc((void **)&c->h_stage, 2 * kStagePiece, hipHostMallocDefault));
+    for (int i = 0; i < 2; i++)
+        if (!c->stage_ev[i])
+            HIPCHK(c, hipEventCreateWithFlags(&c->stage_ev[i], hipEventDisableTiming));
+    return SG_OK;
+}
+
+static void expand_records(const WireRec *w, size_t n, sg_keypoint *out)
+{
+    for (size_t i = 0; i < n; i++) {
+        const WireRec &r = w[i];
+        sg_keypoint &k = out[i];
+        memset(&k, 0, offsetof(sg_keypoint, descriptor)); // padding bytes too: records are byte-reproducible
+        k.octave = r.octave; k.interval = r.interval; k.offset_interval = r.offi;
+        k.x = r.x; k.y = r.y; k.scale = r.scale; k.dx = r.dx; k.dy = r.dy;
+        k.offset_x = r.offx; k.offset_y = r.offy; k.octave_scale = r.oscale; k.ori = r.ori;
+        k.descr_length = 128;
+        for (int q = 0; q < 128; q++)
+            k.descriptor[q] = (double)r.desc[q];
+        k.val = r.val;
     }
-    const size_t pieces = (bytes + kStagePiece - 1) / kStagePiece;
+}
+
+// d_wire: n WireRec records on the device -> out[0..n)
+static int download_records(sg_ctx *c, sg_keypoint *out, const WireRec *d_wire, size_t n)
+{
+    int rc = ensure_stage(c);
+    if (rc != SG_OK)
+        return rc;
+    const size_t pieces = (n + kStageRecs - 1) / kStageRecs;
     for (size_t i = 0; i <= pieces; i++) {
         if (i < pieces) {
-            const size_t off = i * kStagePiece, len = bytes - off < kStagePiece ? bytes - off : kStagePiece;
-            HIPCHK(c, hipMemcpyAsync(c->h_stage + (i & 1) * kStagePiece, (const char *)d_src + off, len,
+            const size_t first = i * kStageRecs, cnt = std::min(kStageRecs, n - first);
+            HIPCHK(c, hipMemcpyAsync(c->h_stage + (i & 1) * kStagePiece, d_wire + first, cnt * sizeof(WireRec),
                                      hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipEventRecord(c->stage_ev[i & 1], c->stream));
         }
-        if (i >= 1) { // piece i-1 has landed once its event has passed; its half is refilled by piece i+1, issued after this copy
-            const size_t off = (i - 1) * kStagePiece, len = bytes - off < kStagePiece ? bytes - off : kStagePiece;
+        if (i >= 1) { // piece i-1 has landed once its event has passed; its half is refilled by piece i+1, issued after this
+            const size_t first = (i - 1) * kStageRecs, cnt = std::min(kStageRecs, n - first);
             HIPCHK(c, hipEventSynchronize(c->stage_ev[(i - 1) & 1]));
-            memcpy((char *)dst + off, c->h_stage + ((i - 1) & 1) * kStagePiece, len);
+            expand_records(reinterpret_cast<const WireRec *>(c->h_stage + ((i - 1) & 1) * kStagePiece), cnt, out + first);
         }
     }
     return SG_OK;
@@ -729,10 +788,7 @@ int sg_create(const sg_params *p, sg_ctx **out)
     c->prm = *p;
     c->B = p->max_batch;
     c->esize = p->precision == SG_F64 ? 8 : 4;
-    {
-        const char *e = getenv("SIFTGPU_BLUR");
-        c->fused_blur = !(e && strcmp(e, "2pass") == 0);
-    }
+    c->fused_blur = env().blur_mode != 1; // the switches are read here, once per process
     memset(c->stage_ms, 0, sizeof c->stage_ms);
     memset(c->stage_launches, 0, sizeof c->stage_launches);
 
@@ -850,6 +906,27 @@ int sg_create(const sg_params *p, sg_ctx **out)
     return SG_OK;
 }
 
+int sg_required_features(const sg_ctx *c, size_t *max_features)
+{
+    if (!c || !max_features)
+        return SG_E_INVALID;
+    // feat_cap holds keypoints and features, cand_cap = 3 * feat_cap + 4096 holds the 3x3x3 extrema.  When the extrema
+    // overflowed, the later counts were taken on a truncated list: scale them by the truncation and add a margin.
+    // A stage that overflowed handed a truncated list to the stages after it: their counts are scaled up by the
+    // truncation (keypoints -> features, extrema -> both), and a margin is added.
+    double kps = c->last_ov[1], feats = c->last_ov[2];
+    if (kps > c->feat_cap)
+        feats *= kps / c->feat_cap;
+    double need = std::max(kps, feats);
+    if (c->last_ov[0] > c->cand_cap) {
+        const double grow = (double)c->last_ov[0] / c->cand_cap;
+        need = std::max(need * grow, (c->last_ov[0] - 4096.0) / 3.0);
+        need = std::max(need, (double)c->feat_cap * grow);
+    }
+    *max_features = need > 0 ? (size_t)(need * 1.25) + 1024 : 0;
+    return SG_OK;
+}
+
 int sg_sync(sg_ctx *c)
 {
     if (!c)
@@ -881,6 +958,8 @@ int sg_extract_batch(sg_ctx *c, const uint8_t *const *imgs, int n_img, int width
     if (!c || !imgs || !out || !counts || n_img < 1 || n_img > c->B)
         return SG_E_INVALID;
     (void)hipSetDevice(c->prm.device);
+    if (width < 1 || height < 1 || channels < 3 || stride < (size_t)width * channels)
+        return fail(c, SG_E_INVALID, "stride is smaller than a row of pixels");
     size_t img_bytes = stride * (size_t)height;
     int rc = ensure_in(c, img_bytes * n_img);
     if (rc != SG_OK)
@@ -888,8 +967,9 @@ int sg_extract_batch(sg_ctx *c, const uint8_t *const *imgs, int n_img, int width
     rc = ensure_out(c, sizeof(sg_packed_feature) * cap_per_image * n_img);
     if (rc != SG_OK)
         return rc;
-    for (int i = 0; i < n_img; i++)
-        HIPCHK(c, hipMemcpyAsync(c->d_in + img_bytes * i, imgs[i], img_bytes, hipMemcpyHostToDevice, c->stream));
+    for (int i = 0; i < n_img; i++) // the last row of a padded view ends after its pixels, not after its stride
+        HIPCHK(c, hipMemcpyAsync(c->d_in + img_bytes * i, imgs[i], image_bytes(width, height, channels, stride),
+                                 hipMemcpyHostToDevice, c->stream));
     rc = sg_extract_batch_device(c, c->d_in, n_img, width, height, channels, stride, img_bytes,
                                  (sg_packed_feature *)c->d_out, cap_per_image, c->d_outcounts);
     if (rc != SG_OK)
@@ -905,17 +985,19 @@ int sg_extract_batch(sg_ctx *c, const uint8_t *const *imgs, int n_img, int width
     return SG_OK;
 }
 
-int sg_extract(sg_ctx *c, const uint8_t *px, int width, int height, int channels, size_t stride, sg_keypoint *out,
-               size_t cap, size_t *n)
+int sg_extract_begin(sg_ctx *c, const uint8_t *px, int width, int height, int channels, size_t stride, size_t *n)
 {
-    if (!c || !px || !n || (cap && !out))
+    if (!c || !px || !n)
         return SG_E_INVALID;
     (void)hipSetDevice(c->prm.device);
+    c->have_pending = false;
+    if (width < 1 || height < 1 || channels < 3 || stride < (size_t)width * channels)
+        return fail(c, SG_E_INVALID, "stride is smaller than a row of pixels");
     size_t img_bytes = stride * (size_t)height;
     int rc = ensure_in(c, img_bytes);
     if (rc != SG_OK)
         return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_in, px, img_bytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in, px, image_bytes(width, height, channels, stride), hipMemcpyHostToDevice, c->stream));
     rc = run_pipeline(c, c->d_in, 1, width, height, channels, stride, img_bytes);
     if (rc != SG_OK)
         return rc;
@@ -925,15 +1007,42 @@ int sg_extract(sg_ctx *c, const uint8_t *px, int width, int height, int channels
     if (rc != SG_OK)
         return rc;
     *n = nf;
+    c->pending_features = nf;
+    c->have_pending = true;
+    return SG_OK;
+}
+
+int sg_extract_fetch(sg_ctx *c, sg_keypoint *out, size_t cap, size_t *n)
+{
+    if (!c || (cap && !out))
+        return SG_E_INVALID;
+    if (!c->have_pending)
+        return fail(c, SG_E_INVALID, "sg_extract_fetch without a successful sg_extract_begin before it");
+    (void)hipSetDevice(c->prm.device);
+    const size_t nf = c->pending_features;
+    if (n)
+        *n = nf;
     if (nf > cap)
         return fail(c, SG_E_CAPACITY, "output array too small");
     if (nf == 0)
         return SG_OK;
-    rc = ensure_out(c, sizeof(sg_keypoint) * (size_t)nf);
+    int rc = ensure_out(c, sizeof(WireRec) * nf);
     if (rc != SG_OK)
         return rc;
-    pack_phase(c, c->d_out, nf, nf, nullptr, 1, 1, 1);
-    return download_staged(c, out, c->d_out, sizeof(sg_keypoint) * (size_t)nf);
+    pack_phase(c, c->d_out, nf, (unsigned int)nf, nullptr, 3, 1, 1);
+    HIPCHK(c, hipGetLastError());
+    return download_records(c, out, (const WireRec *)c->d_out, nf);
+}
+
+int sg_extract(sg_ctx *c, const uint8_t *px, int width, int height, int channels, size_t stride, sg_keypoint *out,
+               size_t cap, size_t *n)
+{
+    if (!c || !px || !n || (cap && !out))
+        return SG_E_INVALID;
+    int rc = sg_extract_begin(c, px, width, height, channels, stride, n);
+    if (rc != SG_OK)
+        return rc;
+    return sg_extract_fetch(c, out, cap, n);
 }
 
 // ---- inspection -------------------------------------------------------------------------------------------
@@ -1385,8 +1494,9 @@ int blur_tmp(sg_ctx *c, const Plane &src, const Plane &dst, double sigma)
     TmpPlane tmp(c, src.rows, src.cols);
     if (!tmp.ok())
         return fail(c, SG_E_NOMEM, "out of device memory");
-    launch_blur_row(src, tmp.pl, 1, taps.data(), n, c->prm.precision, c->stream);
-    launch_blur_col(tmp.pl, dst, 1, taps.data(), n, c->prm.precision, c->stream);
+    if (!launch_blur_row(src, tmp.pl, 1, taps.data(), n, c->prm.precision, c->stream) ||
+        !launch_blur_col(tmp.pl, dst, 1, taps.data(), n, c->prm.precision, c->stream))
+        return fail(c, SG_E_NOMEM, "out of device memory (blur taps)");
     return finish(c);
 }
 
@@ -1440,13 +1550,13 @@ extern "C" {
 
 int sg_convert_to_gray(sg_ctx *c, const uint8_t *px, int width, int height, int channels, size_t stride, double *dst)
 {
-    if (!c || !px || !dst || width < 1 || height < 1 || channels < 3)
+    if (!c || !px || !dst || width < 1 || height < 1 || channels < 3 || stride < (size_t)width * channels)
         return SG_E_INVALID;
     (void)hipSetDevice(c->prm.device);
     int rc = ensure_in(c, stride * (size_t)height);
     if (rc != SG_OK)
         return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_in, px, stride * (size_t)height, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in, px, image_bytes(width, height, channels, stride), hipMemcpyHostToDevice, c->stream));
     TmpPlane out(c, height, width);
     if (!out.ok())
         return fail(c, SG_E_NOMEM, "out of device memory");
@@ -1509,13 +1619,14 @@ int sg_gaussian_smooth(sg_ctx *c, const double *src, double *dst, int width, int
 int sg_create_init_smooth_gray(sg_ctx *c, const uint8_t *px, int width, int height, int channels, size_t stride,
                                double sigma, double *dst)
 {
-    if (!c || !px || !dst || width < 2 || height < 2 || channels < 3 || !(sigma > 1.0))
+    if (!c || !px || !dst || width < 2 || height < 2 || channels < 3 || !(sigma > 1.0) ||
+        stride < (size_t)width * channels)
         return SG_E_INVALID;
     (void)hipSetDevice(c->prm.device);
     int rc = ensure_in(c, stride * (size_t)height);
     if (rc != SG_OK)
         return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_in, px, stride * (size_t)height, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_in, px, image_bytes(width, height, channels, stride), hipMemcpyHostToDevice, c->stream));
     TmpPlane up(c, 2 * height, 2 * width), out(c, 2 * height, 2 * width);
     if (!up.ok() || !out.ok())
         return fail(c, SG_E_NOMEM, "out of device memory");
@@ -1637,7 +1748,6 @@ int sg_detect_local_extrema(sg_ctx *c, const double *const *dog, int width, int 
         return rc;
     if (pyr.n_words > c->words_img)
         return fail(c, SG_E_CAPACITY, "pyramid larger than the context was sized for");
-    (void)hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int) * 4, c->stream);
     detect_phase(c, pyr.tab, pyr.n_words, 1, nointerval);
     rc = check_overflow(c);
     if (rc != SG_OK)
@@ -1686,10 +1796,20 @@ int sg_half_features(sg_keypoint *kp, size_t n)
     return SG_OK;
 }
 
-static int upload_records(sg_ctx *c, const sg_keypoint *recs, size_t n, bool with_ori)
+// Records come from the caller (hand-built, or read from a text file that leaves most fields zero): the kernels index
+// level [octave][interval] at (x, y) and size their windows from octave_scale, so everything they index by is checked.
+static int upload_records(sg_ctx *c, const sg_keypoint *recs, size_t n, bool with_ori, const OctaveTab &tab)
 {
     if (n > c->feat_cap)
         return fail(c, SG_E_CAPACITY, "more records than the context's feature capacity");
+    for (size_t i = 0; i < n; i++) {
+        const sg_keypoint &k = recs[i];
+        const bool ok = k.octave >= 0 && k.octave < tab.octaves && k.interval >= 0 && k.interval < kLevels &&
+                        k.x >= 0 && k.x < tab.cols[k.octave] && k.y >= 0 && k.y < tab.rows[k.octave] &&
+                        k.octave_scale > 0 && k.octave_scale <= 256.0 && (!with_ori || std::isfinite(k.ori));
+        if (!ok) // (a NaN octave_scale fails both comparisons)
+            return fail(c, SG_E_INVALID, "record with octave, interval, x, y, octave_scale or ori outside the pyramid's range");
+    }
     std::vector<KpRec> kp(n);
     std::vector<unsigned int> ident(n), fsrc(n);
     std::vector<double> ori(with_ori ? n * kOriBins : 0);
@@ -1727,10 +1847,9 @@ int sg_orientation_assignment(sg_ctx *c, const sg_keypoint *extrema, size_t n_ex
     int rc = pyr.build(c, gauss, width, height, octaves, kLevels, false);
     if (rc != SG_OK)
         return rc;
-    rc = upload_records(c, extrema, n_extrema, false);
+    rc = upload_records(c, extrema, n_extrema, false, pyr.tab);
     if (rc != SG_OK)
         return rc;
-    (void)hipMemsetAsync(c->d_overflow, 0, sizeof(unsigned int) * 4, c->stream);
     (void)hipMemsetAsync(c->d_chunks + c->chunks1 + c->chunks2, 0, sizeof(unsigned int) * c->chunks3, c->stream);
     int max_radius = 0;
     for (size_t i = 0; i < n_extrema; i++)
@@ -1770,7 +1889,7 @@ int sg_descriptor_representation(sg_ctx *c, sg_keypoint *features, size_t n, con
     int rc = pyr.build(c, gauss, width, height, octaves, kLevels, false);
     if (rc != SG_OK)
         return rc;
-    rc = upload_records(c, features, n, true);
+    rc = upload_records(c, features, n, true, pyr.tab);
     if (rc != SG_OK)
         return rc;
     int max_radius = 0;

@@ -123,6 +123,13 @@ void DrawKeyPointsRight(Mat &src, std::vector<Keypoint> &keypoints, cv::Size siz
 void cv64f_to_cv8U(const Mat &src, Mat &dst);          // min-max normalised to 0..255, rounded (sift.cpp:1843-1847)
 void writecv64f(const char *filename, const Mat &mat); // cv64f_to_cv8U, then the image file (sift.cpp:1858-1863)
 void write_pyr(const std::vector<Mat> &pyr, const char *dir); // every level as <dir><i>.pgm (sift.cpp:1865-1873)
+const char *GetFileName(const char *dir, int i);               // "<dir><i>.jpg" (sift.h:149, sift.cpp:1849-1855); per-thread buffer
+void display_pyr(const std::vector<Mat> &pyr, std::string dir); // prints the dump names (sift.h:153, sift.cpp:1875-1884)
+
+// ---- off-path helpers of the reference, kept so that its callers link (host CPU code) ---------------------------
+void GaussianTemplateSmooth(const Mat &src, Mat &dst);          // fixed 7x7 template on 8-bit images (sift.h:121, sift.cpp:183-236)
+void GaussianSmooth2D(const Mat &src, Mat &dst, double sigma);  // direct 2-D Gaussian on 8-bit gray (sift.h:123, sift.cpp:245-314)
+void testInverse3D();                                           // prints H * inverse(H) for one 3x3 (sift.h:159, sift.cpp:1934-1960)
 
 // ---- additions of this implementation -----------------------------------------------------------------------
 int SiftLastStatus();            // sg_status of the most recent call on this thread (0 = ok)

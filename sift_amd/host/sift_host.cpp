@@ -20,6 +20,7 @@ struct ThreadState {
     int max_w = 0, max_h = 0;
     double sigma = 0;
     int nointerval = -1;
+    size_t max_features = 0; // 0: the library's default density; raised after an image overflowed it
     int device = 0;
     int status = SG_OK;
     std::string error;
@@ -47,16 +48,20 @@ void set_status(int rc, const char *what = nullptr)
         tls.error = sg_strerror(rc);
 }
 
-// A context able to take input images up to w x h (i.e. base planes up to 2w x 2h).
-sg_ctx *context_for(int w, int h, double sigma, int nointerval)
+// A context able to take input images up to w x h (i.e. base planes up to 2w x 2h) with room for at least
+// min_features features per image (0: whatever the current context has).
+sg_ctx *context_for(int w, int h, double sigma, int nointerval, size_t min_features = 0)
 {
     if (w < 2)
         w = 2;
     if (h < 2)
         h = 2;
-    const bool fits = tls.ctx && w <= tls.max_w && h <= tls.max_h && sigma == tls.sigma && nointerval == tls.nointerval;
+    const bool fits = tls.ctx && w <= tls.max_w && h <= tls.max_h && sigma == tls.sigma &&
+                      nointerval == tls.nointerval && min_features <= tls.max_features;
     if (fits)
         return tls.ctx;
+    if (min_features > tls.max_features)
+        tls.max_features = min_features;
     if (tls.ctx) {
         sg_destroy(tls.ctx);
         tls.ctx = nullptr;
@@ -69,6 +74,7 @@ sg_ctx *context_for(int w, int h, double sigma, int nointerval)
     p.max_height = h > tls.max_h ? h : tls.max_h;
     p.max_batch = 1;
     p.device = tls.device;
+    p.max_features = tls.max_features > 0x7fffffff ? 0x7fffffff : (int)tls.max_features;
     int rc = sg_create(&p, &tls.ctx);
     if (rc != SG_OK) {
         tls.ctx = nullptr;
@@ -81,6 +87,17 @@ sg_ctx *context_for(int w, int h, double sigma, int nointerval)
     tls.sigma = sigma;
     tls.nointerval = nointerval;
     return tls.ctx;
+}
+
+// After a call returned SG_E_CAPACITY: if an internal buffer of the context overflowed (an image denser than the
+// default sizing assumes; the reference has no such limit), a context sized from the reported counts replaces it
+// and true is returned: the caller runs the call again.  False when the overflow was the caller's own output array.
+bool grow_context(int w, int h, double sigma, int nointerval)
+{
+    size_t need = 0;
+    if (!tls.ctx || sg_required_features(tls.ctx, &need) != SG_OK || need == 0 || need <= tls.max_features)
+        return false;
+    return context_for(w, h, sigma, nointerval, need) != nullptr;
 }
 
 // context for stage calls on a plane of cols x rows used as (at most) a base image
@@ -141,19 +158,27 @@ void run_sift(const Mat &src, std::vector<Keypoint> &features, double sigma, int
     sg_ctx *ctx = context_for(src.cols, src.rows, sigma, nointerval);
     if (!ctx)
         return;
-    size_t cap = (size_t)src.cols * src.rows / 40 + 4096, n = 0;
-    std::vector<Keypoint> out(cap);
-    int rc = sg_extract(ctx, src.data, src.cols, src.rows, src.channels(), src.step,
-                        reinterpret_cast<sg_keypoint *>(out.data()), cap, &n);
-    if (rc == SG_E_CAPACITY && n > cap) {
-        cap = n;
-        out.resize(cap);
-        rc = sg_extract(ctx, src.data, src.cols, src.rows, src.channels(), src.step,
-                        reinterpret_cast<sg_keypoint *>(out.data()), cap, &n);
+    // Two steps, so that the records are written once, straight behind the features the caller already holds
+    // (the reference appends): the path runs and reports its count, the vector grows, the records come down.
+    size_t n = 0;
+    int rc = SG_OK;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        rc = sg_extract_begin(ctx, src.data, src.cols, src.rows, src.channels(), src.step, &n);
+        if (rc != SG_E_CAPACITY || !grow_context(src.cols, src.rows, sigma, nointerval))
+            break;
+        ctx = tls.ctx;
     }
     set_status(rc);
     if (rc != SG_OK)
         return;
+    const size_t old = features.size();
+    features.resize(old + n);
+    rc = sg_extract_fetch(ctx, reinterpret_cast<sg_keypoint *>(features.data() + old), n, &n);
+    set_status(rc);
+    if (rc != SG_OK) {
+        features.resize(old);
+        return;
+    }
     if (tls.verbose) { // the reference's progress lines (sift.cpp:984-986, 1654-1706)
         sg_counters c;
         sg_read_counters(ctx, 0, &c);
@@ -164,7 +189,6 @@ void run_sift(const Mat &src, std::vector<Keypoint> &features, double sigma, int
         std::cout << "keypoints cout: " << c.cc3 << std::endl;
         std::cout << "features count: " << n << std::endl;
     }
-    features.insert(features.end(), out.begin(), out.begin() + (long)n);
 }
 
 void run_detect(const std::vector<Mat> &dog_pyr, std::vector<Keypoint> &extrema, int octaves, int intervals, int ni)
@@ -195,8 +219,21 @@ void run_detect(const std::vector<Mat> &dog_pyr, std::vector<Keypoint> &extrema,
     size_t cap = (size_t)rows * cols / 40 + 4096, n = 0;
     std::vector<Keypoint> out(cap);
     sg_counters c;
-    int rc = sg_detect_local_extrema(ctx, ptrs.data(), cols, rows, octaves, intervals, ni,
+    int rc = SG_OK;
+    for (int attempt = 0; attempt < 4; attempt++) {
+        rc = sg_detect_local_extrema(ctx, ptrs.data(), cols, rows, octaves, intervals, ni,
                                      reinterpret_cast<sg_keypoint *>(out.data()), cap, &n, &c);
+        if (rc != SG_E_CAPACITY)
+            break;
+        if (n > cap) { // the output array was the small one
+            cap = n;
+            out.resize(cap);
+        } else if (grow_context((cols + 1) / 2, (rows + 1) / 2, tls.sigma, tls.nointerval)) {
+            ctx = tls.ctx;
+        } else {
+            break;
+        }
+    }
     set_status(rc);
     if (rc != SG_OK)
         return;
@@ -238,6 +275,7 @@ void SiftReleaseContext()
         sg_destroy(tls.ctx);
     tls.ctx = nullptr;
     tls.max_w = tls.max_h = 0;
+    tls.max_features = 0;
 }
 
 // ------------------------------------------------------------------------------------------ stages
@@ -438,15 +476,25 @@ void OrientationAssignment(std::vector<Keypoint> &extrema, std::vector<Keypoint>
     }
     size_t cap = 2 * extrema.size() + 64, n = 0;
     std::vector<Keypoint> out(cap);
-    int rc = sg_orientation_assignment(ctx, reinterpret_cast<const sg_keypoint *>(extrema.data()), extrema.size(),
-                                       ptrs.data(), gauss_pyr[0].cols, gauss_pyr[0].rows, octaves,
-                                       reinterpret_cast<sg_keypoint *>(out.data()), cap, &n);
-    if (rc == SG_E_CAPACITY && n > cap) {
-        cap = n;
-        out.resize(cap);
+    int rc = SG_OK;
+    for (int attempt = 0; attempt < 4; attempt++) {
         rc = sg_orientation_assignment(ctx, reinterpret_cast<const sg_keypoint *>(extrema.data()), extrema.size(),
                                        ptrs.data(), gauss_pyr[0].cols, gauss_pyr[0].rows, octaves,
                                        reinterpret_cast<sg_keypoint *>(out.data()), cap, &n);
+        if (rc != SG_E_CAPACITY)
+            break;
+        if (n > cap) {
+            cap = n;
+            out.resize(cap);
+        } else if (grow_context((gauss_pyr[0].cols + 1) / 2, (gauss_pyr[0].rows + 1) / 2, tls.sigma, tls.nointerval)) {
+            ctx = tls.ctx;
+        } else if (extrema.size() > tls.max_features &&
+                   context_for((gauss_pyr[0].cols + 1) / 2, (gauss_pyr[0].rows + 1) / 2, tls.sigma, tls.nointerval,
+                               2 * extrema.size() + 64)) {
+            ctx = tls.ctx; // more records than the context's feature capacity: sized from the input itself
+        } else {
+            break;
+        }
     }
     set_status(rc);
     if (rc == SG_OK)

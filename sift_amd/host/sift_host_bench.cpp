@@ -1,0 +1,96 @@
+// sift_host_bench.cpp -- the reference's own entry point, Sift(const Mat &, vector<Keypoint> &) (sift/sift.h:139),
+// timed as a caller sees it: host image in, 1120-byte records appended to a host vector.
+//   sift_host_bench <width> <height> <threads> <calls per thread> [device]
+// One thread alone gives the latency of a call; T threads, each with its own context (the layer keeps one per thread)
+// and its own frame, give the throughput one GPU delivers through this interface.  Prints one JSON object.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
+#include <vector>
+
+#include "sift_gpu.h"
+#include "synth_image.h"
+
+typedef std::chrono::steady_clock Clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+int main(int argc, char **argv)
+{
+    if (argc < 5) {
+        std::fprintf(stderr, "usage: %s width height threads calls [device]\n", argv[0]);
+        return 2;
+    }
+    const int w = std::atoi(argv[1]), h = std::atoi(argv[2]), T = std::atoi(argv[3]), N = std::atoi(argv[4]);
+    const int device = argc > 5 ? std::atoi(argv[5]) : 0;
+    std::vector<Mat> frames;
+    for (int t = 0; t < (T > 0 ? T : 1); t++)
+        frames.push_back(make_image(w, h, 1000 + (uint64_t)t));
+
+    // ---- one thread: latency of a call (vector reused, as a caller in a loop would) ----
+    SiftSetDevice(device);
+    std::vector<Keypoint> f;
+    Sift(frames[0], f, SIGMA); // creates the context
+    if (SiftLastStatus() != 0) {
+        std::fprintf(stderr, "Sift failed: %s\n", SiftLastError());
+        return 1;
+    }
+    const size_t n_feat = f.size();
+    double best = 1e30, sum = 0;
+    const int reps = N > 0 ? N : 1;
+    for (int i = 0; i < reps; i++) {
+        f.clear();
+        const Clock::time_point t0 = Clock::now();
+        Sift(frames[0], f, SIGMA);
+        const double ms = ms_since(t0);
+        best = ms < best ? ms : best;
+        sum += ms;
+    }
+    double fresh = 0; // a fresh vector per call: the pages of 25 MB of records are faulted in as well
+    for (int i = 0; i < 3; i++) {
+        std::vector<Keypoint> g;
+        const Clock::time_point t0 = Clock::now();
+        Sift(frames[0], g, SIGMA);
+        fresh += ms_since(t0) / 3;
+    }
+
+    // ---- T threads ----
+    std::vector<int> status(T > 0 ? T : 1, 0);
+    std::vector<std::thread> th;
+    std::vector<size_t> counts(T > 0 ? T : 1, 0);
+    // contexts are created before the clock starts
+    std::vector<char> ready(T > 0 ? T : 1, 0);
+    volatile bool go = false;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            SiftSetDevice(device);
+            std::vector<Keypoint> out;
+            Sift(frames[t], out, SIGMA);
+            ready[t] = 1;
+            while (!go)
+                std::this_thread::yield();
+            for (int i = 0; i < N && SiftLastStatus() == 0; i++) {
+                out.clear();
+                Sift(frames[t], out, SIGMA);
+            }
+            status[t] = SiftLastStatus();
+            counts[t] = out.size();
+        });
+    for (int t = 0; t < T; t++)
+        while (!ready[t])
+            std::this_thread::yield();
+    const Clock::time_point t0 = Clock::now();
+    go = true;
+    for (std::thread &x : th)
+        x.join();
+    const double wall = ms_since(t0);
+    for (int t = 0; t < T; t++)
+        if (status[t] != 0) {
+            std::fprintf(stderr, "thread %d failed with status %d\n", t, status[t]);
+            return 1;
+        }
+    std::printf("{\"width\": %d, \"height\": %d, \"features\": %zu, \"sift_ms_single\": %.3f, \"sift_ms_single_best\": %.3f, "
+                "\"sift_ms_fresh_vector\": %.3f, \"threads\": %d, \"calls\": %d, \"images_per_s\": %.1f}\n",
+                w, h, n_feat, sum / reps, best, fresh, T, T * N, T > 0 ? 1e3 * T * N / wall : 0.0);
+    return 0;
+}

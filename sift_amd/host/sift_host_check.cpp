@@ -1,0 +1,100 @@
+// sift_host_check.cpp -- checks of the host layer that need no reference output:
+//   dense <w> <h> <cell> <out.txt>   Sift() on a checkerboard of <cell>-pixel squares, whose features overflow the
+//                                    context's default sizing: the layer must grow the context and return them all
+//   views <w> <h> <seed>             Sift() on a 4-channel frame and on a padded view (step > cols * channels, last
+//                                    row ending at the end of its buffer) equals Sift() on the packed 3-channel frame
+//   legacy                           the reference's off-path helpers (8-bit legacy blurs, dump names)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "sift_gpu.h"
+#include "synth_image.h"
+
+static bool same_features(const std::vector<Keypoint> &a, const std::vector<Keypoint> &b)
+{
+    return a.size() == b.size() && (a.empty() || std::memcmp(a.data(), b.data(), a.size() * sizeof(Keypoint)) == 0);
+}
+
+static int fail(const char *what)
+{
+    std::fprintf(stderr, "FAILED: %s (%s)\n", what, SiftLastError());
+    return 1;
+}
+
+int main(int argc, char **argv)
+{
+    const std::string mode = argc > 1 ? argv[1] : "";
+    if (mode == "dense" && argc == 6) {
+        Mat img = make_checker_image(std::atoi(argv[2]), std::atoi(argv[3]), std::atoi(argv[4]));
+        std::vector<Keypoint> f;
+        Sift(img, f, SIGMA);
+        if (SiftLastStatus() != 0)
+            return fail("Sift on a dense frame");
+        write_features(f, argv[5]);
+        std::vector<Keypoint> again; // the grown context serves the next call directly
+        Sift(img, again, SIGMA);
+        if (SiftLastStatus() != 0 || !same_features(f, again))
+            return fail("second Sift on the dense frame");
+        std::printf("dense ok: %zu features\n", f.size());
+        return 0;
+    }
+    if (mode == "views" && argc == 5) {
+        const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+        Mat img = make_image(w, h, std::strtoull(argv[4], nullptr, 10));
+        std::vector<Keypoint> want, got4, gotv;
+        Sift(img, want, SIGMA);
+        if (SiftLastStatus() != 0 || want.empty())
+            return fail("Sift");
+        Mat four(h, w, CV_8UC4); // b, g, r and a fourth channel the path must ignore
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const unsigned char *s = img.data + img.step * (size_t)y + 3 * (size_t)x;
+                unsigned char *d = four.data + four.step * (size_t)y + 4 * (size_t)x;
+                d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = (unsigned char)(x * 7 + y);
+            }
+        Sift(four, got4, SIGMA);
+        if (SiftLastStatus() != 0 || !same_features(want, got4))
+            return fail("4-channel frame");
+        // a view into a wider parent whose last row ends exactly at the end of the allocation
+        const size_t step = (size_t)3 * w + 40;
+        std::vector<unsigned char> parent((size_t)(h - 1) * step + (size_t)3 * w);
+        for (int y = 0; y < h; y++)
+            std::memcpy(parent.data() + step * (size_t)y, img.data + img.step * (size_t)y, (size_t)3 * w);
+        Mat view(h, w, CV_8UC3, parent.data(), step);
+        Sift(view, gotv, SIGMA);
+        if (SiftLastStatus() != 0 || !same_features(want, gotv))
+            return fail("padded view");
+        std::printf("views ok: %zu features\n", want.size());
+        return 0;
+    }
+    if (mode == "legacy") {
+        Mat g(40, 50, CV_8UC1), out, out2, c3(20, 20, CV_8UC3), out3;
+        for (int y = 0; y < 40; y++)
+            for (int x = 0; x < 50; x++)
+                g.data[g.step * (size_t)y + x] = 100;
+        std::memset(c3.data, 60, (size_t)(c3.dataend - c3.data));
+        GaussianTemplateSmooth(g, out);
+        GaussianSmooth2D(g, out2, 1.0);
+        GaussianTemplateSmooth(c3, out3);
+        // a constant image stays constant up to the truncation of the (not exactly normalised) sums, where a window
+        // centre reaches: rows 3..rows-5, columns 3..cols-5 for the 7x7 kernels
+        const int a = out.data[out.step * 10 + 10], b = out2.data[out2.step * 10 + 10], c = out3.data[out3.step * 8 + 3 * 8 + 1];
+        if (out.rows != 40 || out.cols != 50 || a < 99 || a > 100 || b < 99 || b > 100 || c < 59 || c > 60)
+            return fail("legacy blurs");
+        Mat same;
+        GaussianSmooth2D(g, same, 0.1); // kernel size 1: a copy
+        if (same.rows != 40 || std::memcmp(same.data, g.data, 40 * 50) != 0)
+            return fail("GaussianSmooth2D with a 1x1 kernel");
+        if (std::string(GetFileName("pyr/level", 7)) != "pyr/level7.jpg")
+            return fail("GetFileName");
+        std::vector<Mat> pyr(2);
+        display_pyr(pyr, "dog");
+        testInverse3D();
+        std::printf("legacy ok\n");
+        return 0;
+    }
+    std::fprintf(stderr, "usage: %s dense w h cell out.txt | views w h seed | legacy\n", argv[0]);
+    return 2;
+}

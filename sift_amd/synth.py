@@ -44,3 +44,63 @@ def vnoise5(width, height, seed):
             v = v + A[k] * ((a * (1 - fx) + b * fx) * (1 - fy) + (c * (1 - fx) + d * fx) * fy)
     q = np.clip(np.rint(v), 0, 255).astype(np.uint8)
     return np.repeat(q[:, :, None], 3, axis=2)
+
+
+# ---- inputs that stress what smooth value noise barely touches -------------------------------------------------
+# Flat regions give exact ties in the non-strict extremum test (reference sift/sift.cpp:479-523) and Hessians with
+# |det| < 1e-10 (sift.cpp:738-739); straight edges give Det <= 0 and large Tr^2/Det in the edge test
+# (sift.cpp:616-626); white noise gives far more extrema per pixel than any natural image.
+
+def _gray3(q):
+    return np.repeat(np.ascontiguousarray(q, dtype=np.uint8)[:, :, None], 3, axis=2)
+
+
+def white_noise(width, height, seed):
+    """Every pixel an independent hash of (x, y, seed); b = g = r."""
+    with np.errstate(over="ignore"):
+        xs = np.arange(width, dtype=np.uint64)[None, :]
+        ys = np.arange(height, dtype=np.uint64)[:, None]
+        h = _sm64(np.uint64(seed) ^ _sm64(xs | (ys << np.uint64(32))))
+    return _gray3((h & np.uint64(255)).astype(np.uint8))
+
+
+def checkerboard(width, height, cell=16, lo=0, hi=255):
+    """Saturated squares with step edges and X-corners."""
+    xs = np.arange(width)[None, :] // cell
+    ys = np.arange(height)[:, None] // cell
+    return _gray3(np.where((xs + ys) % 2 == 0, lo, hi))
+
+
+def step_edges(width, height, seed, n=40):
+    """Piecewise-constant image: n random axis-aligned rectangles of random gray level painted over mid-gray."""
+    rng = np.random.RandomState(seed)
+    img = np.full((height, width), 128, dtype=np.uint8)
+    for _ in range(n):
+        x0, y0 = rng.randint(0, width), rng.randint(0, height)
+        w, h = rng.randint(4, max(5, width // 3)), rng.randint(4, max(5, height // 3))
+        img[y0:y0 + h, x0:x0 + w] = rng.randint(0, 256)
+    return _gray3(img)
+
+
+def blobs(width, height, seed, n=60):
+    """Bright and dark Gaussian blobs of random size on mid-gray (scale-space extrema by construction), rounded."""
+    rng = np.random.RandomState(seed)
+    ys, xs = np.mgrid[0:height, 0:width].astype(np.float64)
+    v = np.full((height, width), 128.0)
+    for _ in range(n):
+        cx, cy = rng.uniform(0, width), rng.uniform(0, height)
+        s = rng.uniform(1.5, 12.0)
+        a = rng.choice([-1.0, 1.0]) * rng.uniform(30, 120)
+        v += a * np.exp(-((xs - cx) ** 2 + (ys - cy) ** 2) / (2 * s * s))
+    return _gray3(np.clip(np.rint(v), 0, 255))
+
+
+def saturated_blocks(width, height, seed, n=12):
+    """Value noise with rectangular blocks forced to 0 and to 255 (clipped highlights and shadows)."""
+    rng = np.random.RandomState(seed)
+    img = vnoise5(width, height, seed)[:, :, 0].copy()
+    for i in range(n):
+        x0, y0 = rng.randint(0, width), rng.randint(0, height)
+        w, h = rng.randint(6, max(7, width // 4)), rng.randint(6, max(7, height // 4))
+        img[y0:y0 + h, x0:x0 + w] = 255 if i % 2 else 0
+    return _gray3(img)

@@ -90,3 +90,19 @@ def test_pyramid_dump(outputs):
     assert a.min() == 0 and a.max() == 255
     b = read_pnm(os.path.join(outputs, "lvl1.pgm"))
     assert b.shape == (3, 4) and (b == 0).all()
+
+
+def test_legacy_helpers_link_and_run():
+    """The reference's off-path helpers (8-bit legacy blurs, GetFileName, display_pyr, testInverse3D; sift.h:121-123,
+    149, 153, 159) exist in the host library with the reference's signatures; host code only, no GPU needed."""
+    import subprocess
+    exe = os.path.join(ROOT, "sift_amd", "host", "sift_host_check")
+    if not os.path.exists(exe):
+        pytest.fail("%s is not built (run __graft_entry__.build())" % exe)
+    out = subprocess.run([exe, "legacy"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "legacy ok" in out.stdout and "name: dog 1" in out.stdout
+    # H * inverse(H) printed by testInverse3D is the identity to rounding
+    rows = [l.split() for l in out.stdout.splitlines() if len(l.split()) == 3 and "ok" not in l and "name" not in l]
+    m = np.array(rows[-3:], dtype=float)
+    assert np.allclose(m, np.eye(3), atol=1e-9)

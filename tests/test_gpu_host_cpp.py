@@ -47,3 +47,27 @@ def test_stage_entry_points_equal_driver():
     out = subprocess.run([exe, "160", "120", "77"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "stage chain ok" in out.stdout
+
+
+def test_dense_frame_grows_the_context(oracle, tmp_path):
+    """Sift() on a checkerboard of 3-pixel squares: denser in features than the context's default sizing, where the
+    reference simply returns its result.  The host layer must size a new context from the reported counts and return the same features."""
+    import sift_amd
+    exe = _need("sift_host_check")
+    w, h, cell = 320, 240, 3
+    o = str(tmp_path / "dense.txt")
+    out = subprocess.run([exe, "dense", str(w), str(h), str(cell), o], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    want, _, _, _ = oracle.sift(sift_amd.synth.checkerboard(w, h, cell))
+    assert len(want) > w * h // 40 + 4096
+    r = str(tmp_path / "ref.txt")
+    oracle.write_features(want, r)
+    assert open(o, "rb").read() == open(r, "rb").read()
+    assert "dense ok: %d features" % len(want) in out.stdout
+
+
+def test_four_channel_and_padded_views():
+    exe = _need("sift_host_check")
+    out = subprocess.run([exe, "views", "200", "150", "31"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "views ok" in out.stdout

@@ -15,6 +15,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+
 namespace sg {
 
 // BORDER_REFLECT_101, repeated until in range (planes narrower than the kernel occur in the
@@ -1152,8 +1154,17 @@ static int win_segment_rows(int rows, long long per_row, int R, int waves_per_si
     if (nseg_want < 1)
         nseg_want = 1;
     int seg = (rows + nseg_want - 1) / nseg_want;
-    if (seg < 4 * R)
-        seg = 4 * R;
+    // Shortest segment: 4R rows keep the re-filtered halo rows at a third of the work.  A launch that cannot give every
+    // SIMD a wave even then (one frame alone, the small octaves) is bound by the chain of dependent iterations of
+    // its waves, not by work: there the floor drops to the length that gives one wave per SIMD, down to 8 rows.
+    int floor_rows = 4 * R;
+    const long long one_per_simd = (long long)n_cu * 4;
+    if ((long long)((rows + floor_rows - 1) / floor_rows) * per_row < one_per_simd) {
+        const long long s1 = ((long long)rows * per_row + one_per_simd - 1) / one_per_simd;
+        floor_rows = (int)std::min<long long>(floor_rows, std::max<long long>(8, (s1 + 3) & ~3ll));
+    }
+    if (seg < floor_rows)
+        seg = floor_rows;
     if (seg > rows)
         seg = rows;
     return (seg + 1) & ~1; // even, so that row parity inside a segment is the image's

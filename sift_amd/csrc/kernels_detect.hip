@@ -253,8 +253,16 @@ struct DetectRing {
     static constexpr int WAVE_BYTES = D * ROWSLOT;
 };
 
+// One launch scans a run of octaves [o_begin, o_end): tiles are numbered octave after octave, first[o] is the first
+// tile of octave o (first[o_end] = the launch's tile count).  The small octaves, a few tiles each, then cost no launch
+// of their own: a frame processed alone spends its time on dependent launches, not on work.
+struct DetectTiles {
+    unsigned int first[kMaxOctaves + 1];
+    int o_begin, o_end;
+};
+
 template <typename T, bool FROM_DOG, bool NOINT, int RS, int D>
-__global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned long long *words, size_t words_img,
+__global__ __launch_bounds__(256) void detect_k(OctaveTab tab, DetectTiles dt, unsigned long long *words, size_t words_img,
                                                 unsigned int *chunk_sums, size_t chunks_img,
                                                 unsigned long long *counters, double thresh, unsigned int n_img)
 {
@@ -263,16 +271,21 @@ __global__ __launch_bounds__(256) void detect_k(OctaveTab tab, int o, unsigned l
     __shared__ __align__(16) unsigned char ring[4 * R::WAVE_BYTES];
     __shared__ unsigned int blk_ctr[3];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
-    const int nrows = tab.nrows[o], wpr = tab.wpr[o];
     // Workgroups are handed to the eight XCDs in turn, and each XCD has its own L2.  The launch is one-dimensional
     // and workgroup i works on tile (i % 8) * (n / 8) + i / 8, so that an XCD walks a contiguous run of tiles: the
     // rows two vertically adjacent tiles share are then read by the same XCD, not long apart.
-    const unsigned int gx = (wpr + 3) / 4, gy = (nrows + RS - 1) / RS;
     const unsigned int per_xcd = gridDim.x >> 3;
-    const unsigned int tile = SG_DET_XCD ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
-    if (tile >= gx * gy * n_img)
+    unsigned int tile = SG_DET_XCD ? (blockIdx.x & 7u) * per_xcd + (blockIdx.x >> 3) : blockIdx.x;
+    if (tile >= dt.first[dt.o_end])
         return;
+    int o = dt.o_begin;
+    while (o + 1 < dt.o_end && tile >= dt.first[o + 1]) // uniform over the workgroup
+        o++;
+    tile -= dt.first[o];
+    const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o];
+    const int nrows = tab.nrows[o], wpr = tab.wpr[o];
+    const unsigned int gx = (wpr + 3) / 4, gy = (nrows + RS - 1) / RS;
+    (void)n_img;
     const int b = tile / (gx * gy);
     const unsigned int in_img = tile - b * (gx * gy);
     const int by = in_img / gx, bx = in_img - by * gx;
@@ -434,30 +447,10 @@ static bool detect_staged_ok(const OctaveTab &tab, int o, int prec)
     return true;
 }
 
-void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words, size_t words_img_stride,
-                   unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
-                   double thresh, int nointerval, int prec, hipStream_t s)
+static void launch_detect_direct(const OctaveTab &tab, int o, int B, unsigned long long *words, size_t words_img_stride,
+                                 unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
+                                 double thresh, bool fd, bool ni, int prec, hipStream_t s)
 {
-    if (tab.nrows[o] <= 0 || tab.wpr[o] <= 0)
-        return;
-    bool fd = tab.from_dog != 0, ni = nointerval != 0;
-    if (detect_staged_ok(tab, o, prec)) {
-        constexpr int RS = SG_DET_RS, D = SG_DET_D;
-        const unsigned int tiles = (unsigned int)((tab.wpr[o] + 3) / 4) * ((tab.nrows[o] + RS - 1) / RS) * B;
-        const unsigned int g = (tiles + 7) / 8 * 8;
-#define SG_DET(T, FD, NI)                                                                                              \
-    detect_k<T, FD, NI, RS, D><<<g, 256, 0, s>>>(tab, o, words, words_img_stride, chunk_sums, chunks_img_stride, \
-                                                      counters, thresh, (unsigned int)B)
-        if (prec == SG_F64) {
-            if (fd) { if (ni) SG_DET(double, true, true); else SG_DET(double, true, false); }
-            else { if (ni) SG_DET(double, false, true); else SG_DET(double, false, false); }
-        } else {
-            if (fd) { if (ni) SG_DET(float, true, true); else SG_DET(float, true, false); }
-            else { if (ni) SG_DET(float, false, true); else SG_DET(float, false, false); }
-        }
-#undef SG_DET
-        return;
-    }
     constexpr int RS = 16;
     dim3 g((tab.wpr[o] + 3) / 4, (tab.nrows[o] + RS - 1) / RS, B);
 #define SG_DET(T, FD, NI)                                                                                      \
@@ -471,6 +464,61 @@ void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words
         else { if (ni) SG_DET(float, false, true); else SG_DET(float, false, false); }
     }
 #undef SG_DET
+}
+
+// Scans every octave of the table that has pixels inside the border.  Consecutive octaves the staged kernel can take
+// share one launch; an octave it cannot take (rows not 16-byte aligned, planes of 2 GB and more) gets the direct kernel.
+// Returns the number of launches.
+int launch_detect(const OctaveTab &tab, int B, unsigned long long *words, size_t words_img_stride,
+                  unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
+                  double thresh, int nointerval, int prec, hipStream_t s)
+{
+    const bool fd = tab.from_dog != 0, ni = nointerval != 0;
+    constexpr int RS = SG_DET_RS, D = SG_DET_D;
+    int launches = 0;
+    int o = 0;
+    while (o < tab.octaves) {
+        if (tab.nrows[o] <= 0 || tab.wpr[o] <= 0) {
+            o++;
+            continue;
+        }
+        if (!detect_staged_ok(tab, o, prec)) {
+            launch_detect_direct(tab, o, B, words, words_img_stride, chunk_sums, chunks_img_stride, counters, thresh, fd,
+                                 ni, prec, s);
+            launches++;
+            o++;
+            continue;
+        }
+        DetectTiles dt;
+        for (unsigned int &f : dt.first)
+            f = 0;
+        dt.o_begin = o;
+        unsigned long long tiles = 0;
+        while (o < tab.octaves && tab.nrows[o] > 0 && tab.wpr[o] > 0 && detect_staged_ok(tab, o, prec)) {
+            const unsigned long long t = (unsigned long long)((tab.wpr[o] + 3) / 4) * ((tab.nrows[o] + RS - 1) / RS) * B;
+            if (tiles + t > 0xfffffff0ull)
+                break; // (never with this library's own allocations) the next launch takes it
+            dt.first[o] = (unsigned int)tiles;
+            tiles += t;
+            o++;
+        }
+        dt.o_end = o;
+        dt.first[o] = (unsigned int)tiles;
+        const unsigned int g = (unsigned int)((tiles + 7) / 8 * 8);
+#define SG_DET(T, FD, NI)                                                                                              \
+    detect_k<T, FD, NI, RS, D><<<g, 256, 0, s>>>(tab, dt, words, words_img_stride, chunk_sums, chunks_img_stride,      \
+                                                  counters, thresh, (unsigned int)B)
+        if (prec == SG_F64) {
+            if (fd) { if (ni) SG_DET(double, true, true); else SG_DET(double, true, false); }
+            else { if (ni) SG_DET(double, false, true); else SG_DET(double, false, false); }
+        } else {
+            if (fd) { if (ni) SG_DET(float, true, true); else SG_DET(float, true, false); }
+            else { if (ni) SG_DET(float, false, true); else SG_DET(float, false, false); }
+        }
+#undef SG_DET
+        launches++;
+    }
+    return launches;
 }
 
 // ---- ordered compaction: exclusive scan of per-chunk popcounts, then bit expansion ---------------------

@@ -116,9 +116,10 @@ bool launch_blur_fused_upsampled(const Plane &gray, const Plane &dst, int B, con
 bool blur_fused_decimates(const Plane &src, int n, int prec);
 
 // ---- detection --------------------------------------------------------------------------------
-void launch_detect(const OctaveTab &tab, int o, int B, unsigned long long *words, size_t words_img_stride,
-                   unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
-                   double thresh, int nointerval, int prec, hipStream_t s);
+// all octaves of the table; returns the number of launches
+int launch_detect(const OctaveTab &tab, int B, unsigned long long *words, size_t words_img_stride,
+                  unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
+                  double thresh, int nointerval, int prec, hipStream_t s);
 // exclusive scan of chunk_sums (n_chunks per image) in place; totals[b] = sum (clamped report of overflow)
 void launch_scan(unsigned int *chunk_sums, size_t chunks_img_stride, int n_chunks, unsigned int *totals,
                  unsigned int cap, unsigned int *overflow, int B, hipStream_t s);

@@ -100,9 +100,14 @@ struct StageEvents {
 
 } // namespace
 
+// octaves of at most this many pixels per level (all frames of the batch together) blur levels 4 and 5 on the side stream
+constexpr size_t kSideStreamPixels = 4u << 20;
+
 struct sg_ctx {
     sg_params prm;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;   // levels 4 and 5 of under-filled octaves (run_pipeline)
+    hipEvent_t side_ev[2] = {nullptr, nullptr}; // fork, join
     std::string err;
     int B = 1;
     size_t esize = 8;
@@ -135,6 +140,8 @@ struct sg_ctx {
     size_t plane0_elems = 0, levels_elems = 0;
     unsigned long long *d_words = nullptr, *d_vwords = nullptr, *d_pwords = nullptr;
     size_t words_img = 0, vwords_img = 0, pwords_img = 0;
+    void *d_zero = nullptr; // one allocation for what every batch starts from zero: d_ctr | d_counts | d_chunks
+    size_t zero_bytes = 0;
     unsigned int *d_chunks = nullptr; // three arrays per image: detect, valid, peaks
     size_t chunks1 = 0, chunks2 = 0, chunks3 = 0, chunks_total = 0;
     unsigned int *d_cand = nullptr, *d_kpsrc = nullptr, *d_fsrc = nullptr, *d_rank = nullptr;
@@ -366,19 +373,16 @@ static void detect_phase(sg_ctx *c, const OctaveTab &tab, unsigned int n_words, 
 {
     hipStream_t s = c->stream;
     const int prec = c->prm.precision;
-    (void)hipMemsetAsync(c->d_chunks, 0, sizeof(unsigned int) * c->chunks_total * c->B, s);
-    (void)hipMemsetAsync(c->d_ctr, 0, sizeof(unsigned long long) * 8 * c->B, s);
-    (void)hipMemsetAsync(c->d_counts, 0, sizeof(unsigned int) * 3 * c->B, s);
+    (void)hipMemsetAsync(c->d_zero, 0, c->zero_bytes, s); // chunk sums, counters and counts: one region, one fill
     unsigned int *ch1 = c->d_chunks, *ch2 = c->d_chunks + c->chunks1, *ch3 = ch2 + c->chunks2;
     (void)ch3;
     const double thresh = 0.5 * 0.03 / 3; // 0.5 * DXTHRESHOLD / intervals (sift.cpp:924)
     {
-        int scanned = 0; // octaves that have rows and columns inside the border: the ones launch_detect launches for
-        for (int o = 0; o < tab.octaves; o++)
-            scanned += tab.nrows[o] > 0 && tab.wpr[o] > 0;
-        StageScope sc(c, SG_ST_DETECT, scanned);
-        for (int o = 0; o < tab.octaves; o++)
-            launch_detect(tab, o, B, c->d_words, c->words_img, ch1, c->chunks_total, c->d_ctr, thresh, nointerval, prec, s);
+        StageScope sc(c, SG_ST_DETECT, 0);
+        const int launches = launch_detect(tab, B, c->d_words, c->words_img, ch1, c->chunks_total, c->d_ctr, thresh,
+                                           nointerval, prec, s);
+        if (c->prof)
+            c->stage_launches[SG_ST_DETECT] += launches;
     }
     unsigned int *n_cand = c->d_counts, *n_kp = c->d_counts + c->B;
     {
@@ -480,12 +484,12 @@ static void pack_phase(sg_ctx *c, void *out, size_t out_img_stride, unsigned int
 // blur src -> dst through the context's row-pass scratch plane
 // dec (optional): receives the 2:1 decimated copy of dst when the fused kernel can write it; returns whether it did.
 static bool blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, const double *taps, int n, int slot,
-                        const Plane *dec = nullptr)
+                        const Plane *dec = nullptr, hipStream_t side = nullptr)
 {
     if (c->fused_blur && blur_fused_supported(src, n)) {
         StageScope sc(c, SG_ST_BLUR_COL0 + slot);
         const bool with_dec = dec && blur_fused_decimates(src, n, c->prm.precision);
-        if (launch_blur_fused(src, dst, B, taps, n, c->prm.precision, c->stream, with_dec ? dec : nullptr))
+        if (launch_blur_fused(src, dst, B, taps, n, c->prm.precision, side ? side : c->stream, with_dec ? dec : nullptr))
             return with_dec;
     }
     Plane tmp = src;
@@ -557,6 +561,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
         blur_planes(c, up, c->level[0][0], B, c->taps[0], c->ntaps[0], 0);
     }
     bool have_base = true; // level 0 of the octave is in place
+    bool forked = false;
     for (int o = 0; o < c->octaves; o++) {
         if (!have_base) {
             StageScope sc(c, SG_ST_DOWNSAMPLE);
@@ -567,14 +572,31 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
                 launch_downsample(c->level[o - 1][3], c->level[o][0], B, prec, s);
         }
         have_base = false;
+        // Levels 4 and 5 feed nothing but the extrema scan, while the next octave starts from level 3.  Where a launch
+        // cannot fill the chip (a frame alone, the small octaves of a small batch) the time goes into the chain of
+        // dependent launches, so those two leave the chain: they run on the side stream, beside the next octave's
+        // levels.  (Not while stage events are recorded: they time launches on the main stream, one after another.)
+        const bool side_ok = c->side && !c->prof && c->fused_blur && o + 1 < c->octaves &&
+                             (size_t)B * c->rows[o] * c->cols[o] <= kSideStreamPixels &&
+                             blur_fused_supported(c->level[o][3], c->ntaps[4]) &&
+                             blur_fused_supported(c->level[o][4], c->ntaps[5]);
         for (int l = 1; l < kLevels; l++) {
             // the blur that produces level 3 also writes the next octave's level 0 (its 2:1 decimation) when it can
             const bool want_dec = l == 3 && o + 1 < c->octaves && c->rows[o + 1] != c->rows[o];
+            if (l == 4 && side_ok) {
+                (void)hipEventRecord(c->side_ev[0], s);
+                (void)hipStreamWaitEvent(c->side, c->side_ev[0], 0);
+                forked = true;
+            }
             const bool wrote = blur_planes(c, c->level[o][l - 1], c->level[o][l], B, c->taps[l], c->ntaps[l], l,
-                                           want_dec ? &c->level[o + 1][0] : nullptr);
+                                           want_dec ? &c->level[o + 1][0] : nullptr, l >= 4 && side_ok ? c->side : nullptr);
             if (want_dec && wrote)
                 have_base = true;
         }
+    }
+    if (forked) { // the scan reads every level
+        (void)hipEventRecord(c->side_ev[1], c->side);
+        (void)hipStreamWaitEvent(s, c->side_ev[1], 0);
     }
     if (c->launch_failed)
         return fail(c, SG_E_NOMEM, "out of device memory (blur taps)");
@@ -741,9 +763,9 @@ int sg_destroy(sg_ctx *c)
     (void)hipSetDevice(c->prm.device);
     if (c->stream)
         (void)hipStreamSynchronize(c->stream);
-    void *bufs[] = {c->d_in, c->d_up, c->d_tmp, c->d_levels, c->d_words, c->d_vwords, c->d_pwords, c->d_chunks,
+    void *bufs[] = {c->d_in, c->d_up, c->d_tmp, c->d_levels, c->d_words, c->d_vwords, c->d_pwords, c->d_zero,
                     c->d_cand, c->d_kpsrc, c->d_fsrc, c->d_rank, c->d_kp, c->d_ori, c->d_pq, c->d_fscale, c->d_desc,
-                    c->d_counts, c->d_ctr, c->d_overflow, c->d_out, c->d_outcounts, c->d_bwork, c->d_blist, c->d_rtot, c->d_frec};
+                    c->d_overflow, c->d_out, c->d_outcounts, c->d_bwork, c->d_blist, c->d_rtot, c->d_frec};
     for (void *b : bufs)
         if (b)
             (void)hipFree(b);
@@ -762,6 +784,13 @@ int sg_destroy(sg_ctx *c)
             (void)hipEventDestroy(c->ev.start[i]);
             (void)hipEventDestroy(c->ev.stop[i]);
         }
+    if (c->side) {
+        (void)hipStreamSynchronize(c->side);
+        (void)hipStreamDestroy(c->side);
+    }
+    for (hipEvent_t e : c->side_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     if (c->stream)
         (void)hipStreamDestroy(c->stream);
     delete c;
@@ -850,12 +879,17 @@ int sg_create(const sg_params *p, sg_ctx **out)
         delete c;
         return SG_E_HIP;
     }
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side_ev[1], hipEventDisableTiming) != hipSuccess) {
+        sg_destroy(c);
+        return SG_E_HIP;
+    }
     {
         hipError_t e = hipSuccess;
         c->static_scratch = static_scratch_for(p->device, &e); // p->device is current (hipSetDevice above)
         if (!c->static_scratch) {
-            (void)hipStreamDestroy(c->stream);
-            delete c;
+            sg_destroy(c);
             return SG_E_HIP;
         }
     }
@@ -865,7 +899,14 @@ int sg_create(const sg_params *p, sg_ctx **out)
     ALLOC(c->d_words, sizeof(unsigned long long) * c->words_img * B);
     ALLOC(c->d_vwords, sizeof(unsigned long long) * c->vwords_img * B);
     ALLOC(c->d_pwords, sizeof(unsigned long long) * c->pwords_img * B);
-    ALLOC(c->d_chunks, sizeof(unsigned int) * c->chunks_total * B);
+    {
+        const size_t ctr_b = sizeof(unsigned long long) * 8 * B, cnt_b = (sizeof(unsigned int) * 3 * B + 15) & ~(size_t)15;
+        c->zero_bytes = ctr_b + cnt_b + sizeof(unsigned int) * c->chunks_total * B;
+        ALLOC(c->d_zero, c->zero_bytes);
+        c->d_ctr = (unsigned long long *)c->d_zero;
+        c->d_counts = (unsigned int *)((char *)c->d_zero + ctr_b);
+        c->d_chunks = (unsigned int *)((char *)c->d_zero + ctr_b + cnt_b);
+    }
     ALLOC(c->d_cand, sizeof(unsigned int) * (size_t)c->cand_cap * B);
     ALLOC(c->d_kp, sizeof(KpRec) * (size_t)c->cand_cap * B);
     ALLOC(c->d_kpsrc, sizeof(unsigned int) * (size_t)c->feat_cap * B);
@@ -877,8 +918,6 @@ int sg_create(const sg_params *p, sg_ctx **out)
     ALLOC(c->d_desc, (size_t)c->feat_cap * 128 * B);
     if (p->keep_prequant)
         ALLOC(c->d_pq, sizeof(double) * (size_t)c->feat_cap * 128 * B);
-    ALLOC(c->d_counts, sizeof(unsigned int) * 3 * B);
-    ALLOC(c->d_ctr, sizeof(unsigned long long) * 8 * B);
     ALLOC(c->d_overflow, sizeof(unsigned int) * 4);
     ALLOC(c->d_outcounts, sizeof(unsigned int) * B);
     ALLOC(c->d_bwork, sizeof(unsigned int) * 2 * kRankBuckets * B);
@@ -899,7 +938,7 @@ int sg_create(const sg_params *p, sg_ctx **out)
     (void)hipMemset(c->d_words, 0, sizeof(unsigned long long) * c->words_img * B);
     (void)hipMemset(c->d_vwords, 0, sizeof(unsigned long long) * c->vwords_img * B);
     (void)hipMemset(c->d_pwords, 0, sizeof(unsigned long long) * c->pwords_img * B);
-    (void)hipMemset(c->d_counts, 0, sizeof(unsigned int) * 3 * B);
+    (void)hipMemset(c->d_zero, 0, c->zero_bytes);
     (void)hipMemset(c->d_overflow, 0, sizeof(unsigned int) * 4);
     (void)hipDeviceSynchronize();
     *out = c;

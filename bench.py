@@ -11,9 +11,12 @@ ordering, 144-byte packed features).  With the defaults 4 steps x 64 frames = th
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-N > 1: one process per GPU, frames sharded by rank (no data-path exchange during extraction); after every
-step the ranks all-gather their packed feature sets over RCCL (overlapped with the next step's kernels).
-Rank 0 prints one JSON line.
+N > 1: one process per GPU, frames sharded by rank as in the 4096-frame config (global frame f has seed 1000 + f and
+lives on rank f // 512; no data-path exchange during extraction); after every step the ranks all-gather their packed
+feature sets (sg_allgather_features of the C ABI: an all-gather-v over RCCL, overlapped with the next step's
+kernels).  Rank 0 prints one JSON line.  Outside the timed region the line also gets: a check of the last batch
+against the same frames run alone, single-frame latencies (1080p and 8K), and the throughput of the reference's own
+entry point Sift() through the host C++ layer.
 """
 import argparse
 import json
@@ -82,6 +85,86 @@ def measured_traffic(kernel, tname, batch, width, height):
     return None
 
 
+def batch_check_and_latency(sift_amd, torch, dev, dev_index, prec, W, H, cap, frames, frame_bytes, first, B, out, counts):
+    """Outside the timed region: every frame of the last timed batch run alone (a context of one frame) must give the
+    same count and the same packed bytes as it did inside the batch (Sift() is a function of one frame's pixels,
+    reference sift/sift.cpp:1646-1707).  The same context then times single frames: the 1080p frame of the
+    single-image config and, in a context of its own, the 8K one."""
+    one = sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=1, precision=prec, device=dev_index)
+    tmp = torch.empty(cap * 144, dtype=torch.uint8, device=dev)
+    cnt1 = torch.zeros(1, dtype=torch.int32, device=dev)
+    bad_counts = bad_bytes = 0
+    total1 = 0
+    for i in range(B):
+        one.extract_batch_device(frames.data_ptr() + (first + i) * frame_bytes, 1, W, H, 3, tmp.data_ptr(), cap,
+                                 cnt1.data_ptr())
+        one.sync()
+        n = int(cnt1.item())
+        total1 += n
+        if n != int(counts[i]):
+            bad_counts += 1
+        elif not torch.equal(tmp[: n * 144], out[i * cap * 144: i * cap * 144 + n * 144]):
+            bad_bytes += 1
+    verify = {"frames": B, "features_batch": int(counts.astype(np.int64).sum()), "features_frames_alone": total1,
+              "frames_with_other_count": bad_counts, "frames_with_other_bytes": bad_bytes,
+              "ok": bad_counts == 0 and bad_bytes == 0}
+
+    def median_ms(fn, reps):
+        t = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            fn()
+            t.append(1e3 * (time.perf_counter() - t0))
+        return float(np.median(t))
+
+    def one_frame(ctx, w, h, d_img, d_out, c, d_cnt):
+        ctx.extract_batch_device(d_img, 1, w, h, 3, d_out, c, d_cnt)
+        ctx.sync()
+
+    latency = {}
+    if (W, H) == (1920, 1080):
+        args1 = (one, W, H, frames.data_ptr() + first * frame_bytes, tmp.data_ptr(), cap, cnt1.data_ptr())
+        one_frame(*args1)
+        latency["1080p_frame_alone_device"] = median_ms(lambda: one_frame(*args1), 20)
+    one.close()
+    del tmp
+    try:  # the 8K single image (7680x4320, 11 octaves, 15360x8640 base)
+        w8, h8, cap8 = 7680, 4320, 400000
+        big = sift_amd.SiftGPU(max_width=w8, max_height=h8, max_batch=1, precision=prec, device=dev_index)
+        img8 = torch.empty(w8 * h8 * 3, dtype=torch.uint8, device=dev)
+        out8 = torch.empty(cap8 * 144, dtype=torch.uint8, device=dev)
+        big.synth_vnoise5(img8.data_ptr(), w8, h8, 1234)
+        args8 = (big, w8, h8, img8.data_ptr(), out8.data_ptr(), cap8, cnt1.data_ptr())
+        one_frame(*args8)
+        latency["8k_frame_alone_device"] = median_ms(lambda: one_frame(*args8), 5)
+        latency["8k_features"] = int(cnt1.item())
+        big.close()
+    except Exception as e:  # a report, never a dependency of the measured path
+        latency["8k_error"] = repr(e)
+    return verify, latency
+
+
+def host_api_throughput(W, H, dev_index, cpu_threads):
+    """Sift(const Mat &, vector<Keypoint> &) (reference sift/sift.h:139) through the host C++ layer, as a compiled
+    program: latency of one call, and calls per second with one context per host thread."""
+    import subprocess
+    exe = os.path.join(ROOT, "sift_amd", "host", "sift_host_bench")
+    if not os.path.exists(exe):
+        return {"error": "%s is not built" % exe}
+    threads = cpu_threads or min(16, os.cpu_count() or 1)
+    try:
+        p = subprocess.run([exe, str(W), str(H), str(threads), "12", str(dev_index)], capture_output=True, text=True,
+                           timeout=240)
+        if p.returncode != 0:
+            return {"error": p.stderr.strip()[-300:]}
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        r["what"] = ("Sift() on host images, 1120-byte records appended to a host vector; sift_ms_single = one thread, "
+                     "one call at a time; images_per_s = %d host threads, one context each, one GPU" % threads)
+        return r
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -93,7 +176,11 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--precision", choices=("f64", "f32"), default="f64")
-    ap.add_argument("--pool", type=int, default=256, help="distinct frames kept resident per GPU")
+    ap.add_argument("--pool", type=int, default=0,
+                    help="distinct frames kept resident per GPU (0: 256 on one GPU, 512 per rank on several -- the\n"
+                         "256-frame and the 4096-frames-over-8-GPUs configurations)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the untimed extras (batch check, single-frame latencies, host-API throughput)")
     ap.add_argument("--cap", type=int, default=26624, help="packed-feature capacity per frame")
     ap.add_argument("--contexts", type=int, default=1,
                     help="batches in flight per GPU (1: per-kernel event times are undisturbed; 2 overlaps\n"
@@ -132,6 +219,8 @@ def main():
             dist.init_process_group(backend)
 
     W, H, B, K, WU = args.width, args.height, args.batch, args.steps, args.warmup
+    if args.pool <= 0:
+        args.pool = 256 if world == 1 else 512
     prec = sift_amd.SG_F64 if args.precision == "f64" else sift_amd.SG_F32
     esize = 8 if prec == sift_amd.SG_F64 else 4
     nctx = max(1, min(args.contexts, 4))
@@ -171,7 +260,7 @@ def main():
     pool -= pool % B
     frame_bytes = W * H * 3
     frames = torch.empty(pool * frame_bytes, dtype=torch.uint8, device=dev)
-    seed0 = 1000 + rank * 65536
+    seed0 = 1000 + rank * pool  # global frame f = rank * pool + i has seed 1000 + f (f // 512 = rank at the default pool)
     for i in range(pool):
         ctxs[0].synth_vnoise5(frames.data_ptr() + i * frame_bytes, W, H, seed0 + i)
     ctxs[0].sync()
@@ -182,19 +271,33 @@ def main():
     nbuf = nctx if world == 1 else max(2, nctx)
     outs = [torch.empty(B * cap * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    exchange = xctx = comm = None
     if world > 1:
-        g_outs = [torch.empty(world * B * cap * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+        # The exchange step: all-gather-v of the ranks' feature sets (sg_allgather_features: counts first, then one
+        # grouped set of RCCL broadcasts into an unpadded buffer).  It runs on the stream of a context of its own, so
+        # that it overlaps the next step's kernels.  Rehearsals over gloo (several ranks on one GPU, where RCCL cannot
+        # run) take the same exchange through torch.distributed.
+        cap_all = world * B * cap
+        g_outs = [torch.empty(cap_all * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         g_cnts = [torch.zeros(world * B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-    handles = [None] * nbuf      # all-gather in flight on buffer b
-    pending = [None] * nctx      # buffer that context c's batch in flight writes
+        if dist.get_backend() == "nccl":
+            xctx = sift_amd.SiftGPU(max_width=64, max_height=64, max_batch=1, device=dev_index)
+            ids = [sift_amd.api.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = xctx.comm_create(ids[0], rank, world)
+            exchange = "sg_allgather_features (RCCL all-gather-v)"
+        else:
+            exchange = "torch.distributed all-gather-v (%s rehearsal)" % dist.get_backend()
+    gathered_total = [0] * nbuf   # features in the gathered buffer b
+    gather_busy = [False] * nbuf  # all-gather in flight on buffer b
+    pending = [None] * nctx       # buffer that context c's batch in flight writes
 
     def wait_gather(b):
         """Buffer b's all-gather (if any) has completed when this returns."""
-        if handles[b] is not None:
-            for hnd in handles[b]:
-                hnd.wait()
-            handles[b] = None
-            torch.cuda.current_stream().synchronize()
+        if gather_busy[b]:
+            if xctx is not None:
+                xctx.sync()
+            gather_busy[b] = False
 
     def retire(c):
         """Wait for context c's batch; hand its features to the all-gather."""
@@ -204,8 +307,14 @@ def main():
         ctxs[c].sync()
         pending[c] = None
         if world > 1:
-            _, _, handles[b] = sdist.allgather_features(outs[b], cnts[b], async_op=True, out=g_outs[b],
-                                                        out_counts=g_cnts[b])
+            if xctx is not None:
+                first = xctx.allgather_features(comm, outs[b].data_ptr(), cnts[b].data_ptr(), B, cap,
+                                                g_outs[b].data_ptr(), cap_all, g_cnts[b].data_ptr(), world)
+                gathered_total[b] = first[-1]
+                gather_busy[b] = True
+            else:
+                gv, gc, first = sdist.allgather_features_v(outs[b].cpu(), cnts[b].cpu(), cap)
+                gathered_total[b] = first[-1]
 
     def submit(step):
         c, b = step % nctx, step % nbuf
@@ -264,11 +373,25 @@ def main():
             stage_launches[k] = stage_launches.get(k, 0) + ln
         c.set_profiling(False)
     feat_counts = cnts[last_buf[0]].cpu().numpy()
+    gathered_last = gathered_total[last_buf[0]] if world > 1 else None
 
+    last_first = ((WU + K - 1) * B) % pool  # first frame of the last step's batch
+    for c in ctxs:
+        c.close()
+    if world > 1 and xctx is not None:
+        xctx.comm_destroy(comm)
+        xctx.close()
+
+    # ---- untimed extras (rank 0; the other ranks are done) ----
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
         return
+    verify = latency = host_api = None
+    if not args.no_extras:
+        verify, latency = batch_check_and_latency(sift_amd, torch, dev, dev_index, prec, W, H, cap, frames, frame_bytes,
+                                                  last_first, B, outs[last_buf[0]], feat_counts)
+        host_api = host_api_throughput(W, H, dev_index, args.cpu_threads)
 
     images = K * B * world
     value = images / elapsed
@@ -376,11 +499,15 @@ def main():
         "dtype": "f64" if esize == 8 else "f32", "data": "synthetic",
         "config": {"workload": "%d frames %dx%d per GPU (%d steps x %d frames, vnoise5 seeds %d..), sigma 1.6, "
                                "3 intervals, double-size base, packed 144-B features%s"
-                               % (K * B, W, H, K, B, seed0, ", RCCL all-gather per step" if world > 1 else ""),
+                               % (K * B, W, H, K, B, seed0,
+                                  (", %d distinct frames per rank (global frame f: seed 1000 + f, rank f // %d), "
+                                   "all-gather-v of the feature sets after every step" % (pool, pool)) if world > 1 else ""),
                    "batch": B, "contexts_in_flight": nctx, "precision": args.precision,
                    "features_per_frame_last_batch": [int(x) for x in feat_counts[:4]]},
         "images_per_sec_per_gpu": value / world,
         "roofline": roofline, "cpu_baseline": cpu_baseline,
+        "batch_check": verify, "latency_ms": latency, "host_api": host_api, "exchange": exchange,
+        "features_last_step": int(feat_counts.astype(np.int64).sum()), "features_gathered_last_step": gathered_last,
         "stage_ms_per_step": {k: v / K for k, v in stage_ms.items() if v > 0},
         "blur_kernels": blur, "detect_kernel": detect,
     }

@@ -240,6 +240,33 @@ int sg_match_packed_device_noalloc(sg_ctx *ctx, const sg_packed_feature *d_f1, u
                                    const sg_packed_feature *d_f2, uint32_t n2, double ratio, int32_t *d_index2,
                                    uint32_t *d_dist2);
 
+/* ---- multi-GPU: the one exchange step ------------------------------------------------------------------------
+ * The reference has no multi-GPU path (it has no parallelism at all); frames are independent (Sift() is a pure
+ * function of one image, sift/sift.cpp:1646-1707), so a batch is sharded by frame, one rank per GPU, and the only
+ * exchange is the all-gather of the ranks' packed feature sets after extraction.
+ *
+ * sg_allgather_features: every rank passes the output of its sg_extract_batch_device call (d_feats: n_img slots of
+ * cap_per_image features, d_counts: n_img counts; the same n_img and cap_per_image on every rank) and receives in
+ * d_all the features of all ranks' frames, rank after rank, frame after frame, without padding, in d_all_counts
+ * ([n_ranks][n_img], device) every frame's count, and in rank_first (host, n_ranks + 1 entries) the index of each
+ * rank's first feature in d_all (rank_first[n_ranks] = total).  SG_E_CAPACITY when the total exceeds cap_all.
+ * `comm` is an RCCL communicator (ncclComm_t, passed as void* so that this header needs no rccl.h) created by the
+ * caller or by sg_comm_create; NULL means a single rank (no RCCL call is made).  The counts are all-gathered and read
+ * by the host (one stream synchronisation); the features then move as one grouped set of ncclBroadcast calls,
+ * asynchronous on the context's stream (sg_sync waits).  Call it on a context whose stream is not the one a next
+ * batch is being extracted on if the exchange is to overlap that extraction. */
+#define SG_COMM_ID_BYTES 128
+int sg_comm_unique_id(void *id /* SG_COMM_ID_BYTES, filled on one rank and handed to all */);
+int sg_comm_create(sg_ctx *ctx, const void *id, int rank, int n_ranks, void **comm); /* on ctx's device */
+int sg_comm_destroy(void *comm);
+int sg_allgather_features(sg_ctx *ctx, void *comm, const sg_packed_feature *d_feats, const uint32_t *d_counts,
+                          int n_img, size_t cap_per_image, sg_packed_feature *d_all, size_t cap_all,
+                          uint32_t *d_all_counts, size_t *rank_first);
+/* The local half of that step on its own: n_img padded slots -> frames back to back at d_out (room for the sum of
+ * the counts; 16-byte aligned).  Asynchronous on the context's stream. */
+int sg_compact_features(sg_ctx *ctx, const sg_packed_feature *d_feats, const uint32_t *d_counts, int n_img,
+                        size_t cap_per_image, sg_packed_feature *d_out);
+
 /* ---- device memory and synthetic input (so that callers need no HIP binding of their own) ---- */
 
 int sg_malloc(sg_ctx *ctx, size_t bytes, void **d_ptr);

@@ -39,7 +39,8 @@ EXPORTS = (
     "sg_level_dims", "sg_read_level", "sg_read_counters", "sg_read_keypoints", "sg_read_features_unsorted",
     "sg_set_profiling", "sg_get_stage_times", "sg_reset_stage_times", "sg_malloc", "sg_free", "sg_memcpy_h2d",
     "sg_memcpy_d2h", "sg_synth_vnoise5", "sg_match", "sg_match_packed_device",
-    "sg_match_packed_device_noalloc",
+    "sg_match_packed_device_noalloc", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy",
+    "sg_allgather_features", "sg_compact_features",
 )
 
 
@@ -113,6 +114,11 @@ def load_library():
     L.sg_match.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_double, vp, C.c_size_t, szp]
     L.sg_match_packed_device.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_double, vp, vp]
     L.sg_match_packed_device_noalloc.argtypes = [vp, vp, C.c_uint32, vp, C.c_uint32, C.c_double, vp, vp]
+    L.sg_comm_unique_id.argtypes = [vp]
+    L.sg_comm_create.argtypes = [vp, vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.sg_comm_destroy.argtypes = [vp]
+    L.sg_allgather_features.argtypes = [vp, vp, vp, vp, C.c_int, C.c_size_t, vp, C.c_size_t, vp, szp]
+    L.sg_compact_features.argtypes = [vp, vp, vp, C.c_int, C.c_size_t, vp]
     L.sg_last_octaves.argtypes = [vp]
     L.sg_level_dims.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.sg_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
@@ -144,6 +150,15 @@ def _level_ptrs(levels):
     for i, lv in enumerate(levels):
         arr[i] = _dp(lv)
     return arr
+
+
+def comm_unique_id():
+    """128 bytes identifying a new RCCL communicator: made on one rank, handed to all (sg_comm_unique_id)."""
+    buf = C.create_string_buffer(128)
+    rc = load_library().sg_comm_unique_id(buf)
+    if rc != SG_OK:
+        raise SiftGpuError(rc, "RCCL is not available")
+    return buf.raw
 
 
 class SiftGPU:
@@ -377,6 +392,28 @@ class SiftGPU:
     def match_packed_device_noalloc(self, d_f1, n1, d_f2, n2, d_index2, d_dist2=None, ratio=0.5):
         """match_packed_device without any device allocation (static scratch; at most 32768 features per set)."""
         self._check(self.lib.sg_match_packed_device_noalloc(self.ctx, d_f1, n1, d_f2, n2, ratio, d_index2, d_dist2))
+
+    # ---- multi-GPU exchange ------------------------------------------------------------------------------------
+    def comm_create(self, comm_id, rank, n_ranks):
+        """RCCL communicator on this context's device from the 128-byte id of comm_unique_id(); returns a handle."""
+        comm = C.c_void_p()
+        buf = C.create_string_buffer(bytes(comm_id), 128)
+        self._check(self.lib.sg_comm_create(self.ctx, buf, rank, n_ranks, C.byref(comm)))
+        return comm
+
+    def comm_destroy(self, comm):
+        self._check(self.lib.sg_comm_destroy(comm))
+
+    def allgather_features(self, comm, d_feats, d_counts, n_img, cap_per_image, d_all, cap_all, d_all_counts, n_ranks):
+        """All-gather-v of packed features (device pointers as ints); returns rank_first (n_ranks + 1 feature indices).
+        comm None = single rank.  Asynchronous after the counts; sync() before reading d_all."""
+        first = (C.c_size_t * (n_ranks + 1))()
+        self._check(self.lib.sg_allgather_features(self.ctx, comm, d_feats, d_counts, n_img, cap_per_image, d_all,
+                                                   cap_all, d_all_counts, first))
+        return [int(v) for v in first]
+
+    def compact_features(self, d_feats, d_counts, n_img, cap_per_image, d_out):
+        self._check(self.lib.sg_compact_features(self.ctx, d_feats, d_counts, n_img, cap_per_image, d_out))
 
     # ---- inspection ------------------------------------------------------------------------------------
     def last_octaves(self):

@@ -171,4 +171,18 @@ void launch_match(const signed char *rows1, const int *norms1, unsigned int n1, 
                   const int *norms2, unsigned int n2, double ratio, int *index2, unsigned int *dist2, void *partials,
                   unsigned int slices, hipStream_t s);
 
+// ---- multi-GPU exchange (sg_comm.hip) ------------------------------------------------------------------------------
+// [n_img][cap] padded feature slots -> frames back to back at out (16-byte aligned)
+void launch_compact_feats(const sg_packed_feature *in, const unsigned int *counts, int n_img, size_t cap,
+                          sg_packed_feature *out, hipStream_t s);
+// RCCL bound at run time; the int results are ncclResult_t values (0 = success), -1 when RCCL cannot be loaded
+const char *rccl_unavailable_reason(); // nullptr when RCCL is usable
+int rccl_unique_id(void *id128);
+int rccl_comm_create(const void *id128, int rank, int n_ranks, void **comm);
+int rccl_comm_destroy(void *comm);
+int rccl_comm_shape(void *comm, int *rank, int *n_ranks);
+const char *rccl_error_string(int rc);
+int rccl_allgather_u32(void *comm, const unsigned int *send, unsigned int *recv, size_t count, hipStream_t s);
+int rccl_allgatherv_bytes(void *comm, char *base, const size_t *first_byte, int n_ranks, hipStream_t s);
+
 } // namespace sg

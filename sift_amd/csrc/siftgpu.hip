@@ -1459,6 +1459,106 @@ int sg_match(sg_ctx *c, const sg_keypoint *f1, size_t n1, const sg_keypoint *f2,
     return m > cap ? SG_E_CAPACITY : SG_OK;
 }
 
+// ---- multi-GPU exchange ------------------------------------------------------------------------------------------
+
+int sg_comm_unique_id(void *id)
+{
+    if (!id)
+        return SG_E_INVALID;
+    return rccl_unique_id(id) == 0 ? SG_OK : SG_E_UNSUPPORTED;
+}
+
+int sg_comm_create(sg_ctx *c, const void *id, int rank, int n_ranks, void **comm)
+{
+    if (!c || !id || !comm || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return SG_E_INVALID;
+    *comm = nullptr;
+    if (const char *why = rccl_unavailable_reason())
+        return fail(c, SG_E_UNSUPPORTED, why);
+    (void)hipSetDevice(c->prm.device);
+    const int rc = rccl_comm_create(id, rank, n_ranks, comm);
+    if (rc != 0) {
+        c->err = std::string("ncclCommInitRank: ") + rccl_error_string(rc);
+        return SG_E_HIP;
+    }
+    return SG_OK;
+}
+
+int sg_comm_destroy(void *comm)
+{
+    if (!comm)
+        return SG_OK;
+    return rccl_comm_destroy(comm) == 0 ? SG_OK : SG_E_HIP;
+}
+
+int sg_compact_features(sg_ctx *c, const sg_packed_feature *d_feats, const uint32_t *d_counts, int n_img,
+                        size_t cap_per_image, sg_packed_feature *d_out)
+{
+    if (!c || !d_feats || !d_counts || !d_out || n_img < 1)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    launch_compact_feats(d_feats, d_counts, n_img, cap_per_image, d_out, c->stream);
+    HIPCHK(c, hipGetLastError());
+    return SG_OK;
+}
+
+int sg_allgather_features(sg_ctx *c, void *comm, const sg_packed_feature *d_feats, const uint32_t *d_counts, int n_img,
+                          size_t cap_per_image, sg_packed_feature *d_all, size_t cap_all, uint32_t *d_all_counts,
+                          size_t *rank_first)
+{
+    if (!c || !d_feats || !d_counts || !d_all || !d_all_counts || !rank_first || n_img < 1)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    hipStream_t s = c->stream;
+    int rank = 0, n_ranks = 1;
+    if (comm) {
+        if (const char *why = rccl_unavailable_reason())
+            return fail(c, SG_E_UNSUPPORTED, why);
+        const int rc = rccl_comm_shape(comm, &rank, &n_ranks);
+        if (rc != 0 || n_ranks < 1 || rank < 0 || rank >= n_ranks) {
+            c->err = std::string("ncclCommCount/ncclCommUserRank: ") + rccl_error_string(rc);
+            return SG_E_HIP;
+        }
+    }
+    // 1. every rank learns every frame's count
+    if (comm) {
+        const int rc = rccl_allgather_u32(comm, d_counts, d_all_counts, (size_t)n_img, s);
+        if (rc != 0) {
+            c->err = std::string("ncclAllGather: ") + rccl_error_string(rc);
+            return SG_E_HIP;
+        }
+    } else {
+        HIPCHK(c, hipMemcpyAsync(d_all_counts, d_counts, sizeof(uint32_t) * n_img, hipMemcpyDeviceToDevice, s));
+    }
+    std::vector<uint32_t> counts((size_t)n_ranks * n_img);
+    HIPCHK(c, hipMemcpyAsync(counts.data(), d_all_counts, sizeof(uint32_t) * counts.size(), hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    // 2. the layout all ranks derive from the same counts: rank r's features start at rank_first[r]
+    std::vector<size_t> first_byte(n_ranks + 1);
+    rank_first[0] = 0;
+    for (int r = 0; r < n_ranks; r++) {
+        size_t total = 0;
+        for (int i = 0; i < n_img; i++)
+            total += std::min<size_t>(counts[(size_t)r * n_img + i], cap_per_image);
+        rank_first[r + 1] = rank_first[r] + total;
+    }
+    for (int r = 0; r <= n_ranks; r++)
+        first_byte[r] = rank_first[r] * sizeof(sg_packed_feature);
+    if (rank_first[n_ranks] > cap_all)
+        return fail(c, SG_E_CAPACITY, "gathered features do not fit cap_all");
+    // 3. this rank's features into its own slot, without padding; 4. every slot from its owner
+    launch_compact_feats(d_feats, d_counts, n_img, cap_per_image, d_all + rank_first[rank], s);
+    HIPCHK(c, hipGetLastError());
+    if (comm && n_ranks > 1) {
+        const int rc = rccl_allgatherv_bytes(comm, reinterpret_cast<char *>(d_all), first_byte.data(), n_ranks, s);
+        if (rc != 0) {
+            c->err = std::string("ncclBroadcast (all-gather-v): ") + rccl_error_string(rc);
+            return SG_E_HIP;
+        }
+    }
+    return SG_OK;
+}
+
 int sg_synth_vnoise5(sg_ctx *c, uint8_t *d_dst, int width, int height, uint64_t seed)
 {
     if (!c || !d_dst || width < 1 || height < 1)

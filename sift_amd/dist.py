@@ -34,6 +34,43 @@ def allgather_features(packed, counts, group=None, async_op=False, out=None, out
     return out, out_counts, (h1, h2) if async_op else None
 
 
+def allgather_features_v(packed, counts, cap, group=None):
+    """All-gather-v through torch.distributed with the layout of sg_allgather_features (include/siftgpu.h): counts
+    are all-gathered, every rank compacts its frames back to back into its slot of one output buffer, and slot r is
+    broadcast from rank r.  Used where RCCL through the C ABI cannot be (gloo rehearsals on one GPU or on CPU).
+
+    packed: uint8 tensor holding B slots of cap 144-byte features, counts: int32 tensor [B].
+    Returns (all_feats uint8 [total * 144], all_counts int32 [world, B], rank_first list of world + 1 indices)."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    B = counts.numel()
+    all_counts = torch.empty(world * B, dtype=counts.dtype, device=counts.device)
+    dist.all_gather_into_tensor(all_counts, counts.reshape(-1).contiguous(), group=group)
+    per = all_counts.reshape(world, B).clamp(max=cap).to(torch.int64)
+    totals = per.sum(dim=1).cpu().tolist()
+    rank_first = [0]
+    for t in totals:
+        rank_first.append(rank_first[-1] + int(t))
+    out = torch.empty(rank_first[-1] * 144, dtype=torch.uint8, device=packed.device)
+    slots = packed.reshape(B, cap * 144)
+    mine = torch.cat([slots[i, : int(per[rank, i]) * 144] for i in range(B)]) if B else out[:0]
+    out[rank_first[rank] * 144: rank_first[rank + 1] * 144] = mine
+    for r in range(world):
+        if rank_first[r + 1] > rank_first[r]:
+            dist.broadcast(out[rank_first[r] * 144: rank_first[r + 1] * 144], src=dist.get_global_rank(group, r)
+                           if group is not None else r, group=group)
+    return out, all_counts.reshape(world, B), rank_first
+
+
+def unpack_gathered_v(all_feats, all_counts, cap):
+    """Host view of an all-gather-v result: list (global frame order) of PACKED_DTYPE arrays."""
+    flat = all_feats.cpu().numpy().view(PACKED_DTYPE)
+    c = np.minimum(all_counts.cpu().numpy().reshape(-1), cap)
+    ends = np.cumsum(c)
+    return [flat[e - n: e].copy() for e, n in zip(ends, c)]
+
+
 def unpack_gathered(gathered, gathered_counts, batch, cap):
     """Host view of a gathered buffer: list (global frame order) of PACKED_DTYPE arrays."""
     g = gathered.cpu().numpy().view(PACKED_DTYPE).reshape(-1, cap)

@@ -34,7 +34,15 @@ def _worker(rank, world, port, n_frames, batch, cap, result_dir):
         for f, got in enumerate(frames):
             ref = sdist.fake_features(f, 10 + 3 * f, cap)[: 10 + 3 * f]
             assert got.tobytes() == ref.tobytes(), "frame %d on rank %d" % (f, rank)
-        # asynchronous form, as the bench uses it
+        # all-gather-v: the layout of the C ABI's sg_allgather_features (frames back to back, rank after rank)
+        gv, gcv, first = sdist.allgather_features_v(t_packed, t_counts, cap)
+        assert first == [0] + list(np.cumsum([sum(10 + 3 * f for f in range(r * batch, (r + 1) * batch))
+                                              for r in range(world)]))
+        assert gcv.shape == (world, batch) and gv.numel() == first[-1] * 144
+        for f, got in enumerate(sdist.unpack_gathered_v(gv, gcv, cap)):
+            ref = sdist.fake_features(f, 10 + 3 * f, cap)[: 10 + 3 * f]
+            assert got.tobytes() == ref.tobytes(), "all-gather-v frame %d on rank %d" % (f, rank)
+        # asynchronous form of the padded exchange
         g2, gc2, handles = sdist.allgather_features(t_packed, t_counts, async_op=True)
         for h in handles:
             h.wait()

@@ -179,6 +179,8 @@ def main():
     ap.add_argument("--pool", type=int, default=0,
                     help="distinct frames kept resident per GPU (0: 256 on one GPU, 512 per rank on several -- the\n"
                          "256-frame and the 4096-frames-over-8-GPUs configurations)")
+    ap.add_argument("--exchange", action="store_true",
+                    help="run the all-gather step on one rank too (a communicator of one; N > 1 always runs it)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras (batch check, single-frame latencies, host-API throughput)")
     ap.add_argument("--cap", type=int, default=26624, help="packed-feature capacity per frame")
@@ -227,9 +229,10 @@ def main():
     def buffers_bytes(b):
         """Device memory this script allocates beside the contexts: the resident frames, the packed-feature buffers
         and, with more than one rank, the gathered ones."""
-        nb = nctx if world == 1 else max(2, nctx)
+        ex = world > 1 or args.exchange
+        nb = max(2, nctx) if ex else nctx
         pool_frames = max(b, min(args.pool, (K + WU) * b))
-        return pool_frames * W * H * 3 + nb * b * args.cap * 144 * (1 + (world if world > 1 else 0)) + (1 << 30)
+        return pool_frames * W * H * 3 + nb * b * args.cap * 144 * (1 + (world if ex else 0)) + (1 << 30)
 
     ctxs = None
     while ctxs is None:
@@ -268,11 +271,12 @@ def main():
     cap = args.cap
     # Output buffers: one per context; with more than one rank at least two, so that the all-gather of one step's
     # features never reads a buffer the next step's extraction is writing.
-    nbuf = nctx if world == 1 else max(2, nctx)
+    nbuf = nctx if not (world > 1 or args.exchange) else max(2, nctx)
     outs = [torch.empty(B * cap * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
     exchange = xctx = comm = None
-    if world > 1:
+    do_exchange = world > 1 or args.exchange
+    if do_exchange:
         # The exchange step: all-gather-v of the ranks' feature sets (sg_allgather_features: counts first, then one
         # grouped set of RCCL broadcasts into an unpadded buffer).  It runs on the stream of a context of its own, so
         # that it overlaps the next step's kernels.  Rehearsals over gloo (several ranks on one GPU, where RCCL cannot
@@ -280,10 +284,11 @@ def main():
         cap_all = world * B * cap
         g_outs = [torch.empty(cap_all * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         g_cnts = [torch.zeros(world * B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-        if dist.get_backend() == "nccl":
+        if world == 1 or dist.get_backend() == "nccl":
             xctx = sift_amd.SiftGPU(max_width=64, max_height=64, max_batch=1, device=dev_index)
             ids = [sift_amd.api.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
+            if world > 1:
+                dist.broadcast_object_list(ids, src=0)
             comm = xctx.comm_create(ids[0], rank, world)
             exchange = "sg_allgather_features (RCCL all-gather-v)"
         else:
@@ -306,7 +311,7 @@ def main():
             return
         ctxs[c].sync()
         pending[c] = None
-        if world > 1:
+        if do_exchange:
             if xctx is not None:
                 first = xctx.allgather_features(comm, outs[b].data_ptr(), cnts[b].data_ptr(), B, cap,
                                                 g_outs[b].data_ptr(), cap_all, g_cnts[b].data_ptr(), world)
@@ -373,12 +378,12 @@ def main():
             stage_launches[k] = stage_launches.get(k, 0) + ln
         c.set_profiling(False)
     feat_counts = cnts[last_buf[0]].cpu().numpy()
-    gathered_last = gathered_total[last_buf[0]] if world > 1 else None
+    gathered_last = gathered_total[last_buf[0]] if do_exchange else None
 
     last_first = ((WU + K - 1) * B) % pool  # first frame of the last step's batch
     for c in ctxs:
         c.close()
-    if world > 1 and xctx is not None:
+    if xctx is not None:
         xctx.comm_destroy(comm)
         xctx.close()
 

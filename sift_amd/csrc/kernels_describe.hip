@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                       ((ptrdiff_t)(r.y - radius - 1) * pitch + (r.x - radius - 1));
         const char *gb = reinterpret_cast<const char *>(g0);
         const char *gb_up = reinterpret_cast<const char *>(g0 - pitch), *gb_dn = reinterpret_cast<const char *>(g0 + pitch);
-        const double obin_c = (SG_PI - ori) * (4.0 / SG_PI);
+        const double obin_c = (SG_PI - ori) * (4.0 / SG_PI) + 8.0; // + 8: see the drain loop
 
 #pragma unroll
         for (int q = 0; q < (kDescCopies * kDescCopyStride + 63) / 64; q++)
@@ -456,44 +456,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
             }
             // ---- drain: double arithmetic on the listed samples ----
             // The sample list entry and the four neighbour pixels of the lane's next sample are fetched while the
-            // current sample is processed.
-            unsigned int rn = 0, cn = 0; // next sample's row and column inside the window
-            T nl = 0, nr = 0, nu = 0, nd = 0;
-            auto fetch = [&](int e) {
+            // current sample is processed; two sample slots alternate (the loop body is written twice), so that a
+            // fetched sample is used where it landed.
+            struct Sample {
+                unsigned int r, c; // row and column inside the window
+                T nl, nr, nu, nd;
+            };
+            auto fetch = [&](int e, Sample &sm) {
                 if (packed) {
                     const unsigned int pk = queue[e];
-                    rn = pk >> 8;
-                    cn = pk & 255u;
+                    sm.r = pk >> 8;
+                    sm.c = pk & 255u;
                 } else {
-                    rn = (unsigned int)big_row;
-                    cn = (unsigned int)(big_lo + e);
+                    sm.r = (unsigned int)big_row;
+                    sm.c = (unsigned int)(big_lo + e);
                 }
-                const unsigned int off = ((rn + 1u) * (unsigned int)pitch + (cn + 1u)) * (unsigned int)sizeof(T);
+                const unsigned int off = ((sm.r + 1u) * (unsigned int)pitch + (sm.c + 1u)) * (unsigned int)sizeof(T);
                 const char *p8 = gb + (size_t)off;
-                nl = *reinterpret_cast<const T *>(p8 - sizeof(T));
-                nr = *reinterpret_cast<const T *>(p8 + sizeof(T));
-                nu = *reinterpret_cast<const T *>(gb_up + (size_t)off);
-                nd = *reinterpret_cast<const T *>(gb_dn + (size_t)off);
+                sm.nl = *reinterpret_cast<const T *>(p8 - sizeof(T));
+                sm.nr = *reinterpret_cast<const T *>(p8 + sizeof(T));
+                sm.nu = *reinterpret_cast<const T *>(gb_up + (size_t)off);
+                sm.nd = *reinterpret_cast<const T *>(gb_dn + (size_t)off);
             };
-            if (lane < count)
-                fetch(lane);
-            for (int e = lane; e < count; e += 64) {
-                const unsigned int ri = rn, ci = cn;
-                const int i = (int)ri - radius, jj = (int)ci - radius;
-                const double dx = (double)nr - (double)nl;
-                const double dy = (double)nd - (double)nu;
-                if (e + 64 < count)
-                    fetch(e + 64);
-                const double xbin = __builtin_fma(cs, (double)jj, __builtin_fma(-ss, (double)i, 1.5));
-                const double ybin = __builtin_fma(ss, (double)jj, __builtin_fma(cs, (double)i, 1.5));
-                if (xbin > -1.0 && xbin < 4 && ybin > -1.0 && ybin < 4) {
-                    const double grad_mag = sg_sqrt(dx * dx + dy * dy);
+            auto process = [&](const Sample &sm) {
+                const int i = (int)sm.r - radius, jj = (int)sm.c - radius;
+                const double dx = (double)sm.nr - (double)sm.nl;
+                const double dy = (double)sm.nd - (double)sm.nu;
+                // grid coordinates shifted by one cell (xs = xbin + 1 in (0, 5) for an accepted sample), so that
+                // truncation is the floor and the cell index is never negative
+                const double xs = __builtin_fma(cs, (double)jj, __builtin_fma(-ss, (double)i, 2.5));
+                const double ys = __builtin_fma(ss, (double)jj, __builtin_fma(cs, (double)i, 2.5));
+                if (xs > 0.0 && xs < 5.0 && ys > 0.0 && ys < 5.0) {
+                    const double grad_mag = sg_sqrt_sum(dx * dx + dy * dy);
                     // obin = ((pi - atan2(dy,dx)) - ori) * 8/(2 pi) = obin_c - atan2(dy,dx) in units of pi/4; the
                     // histogram index below wraps by itself, so the angle is not brought into [0, 2 pi) first
+                    // (obin_c carries +8, which keeps the coordinate positive and leaves the index unchanged)
                     const double ax = fabs(dx), ay = fabs(dy);
                     const double mx = __builtin_fmax(ax, ay), mn = __builtin_fmin(ax, ay);
                     double kq;
-                    const double au = sg_atan_split(mn, mx, centres, kq);
+                    const double au = sg_atan_split_sum(mn, mx, centres, kq);
                     double q = __builtin_fma(au, 4.0 / SG_PI, kq);
                     q = ay > ax ? 2.0 - q : q;
                     q = dx < 0.0 ? 4.0 - q : q;
@@ -502,25 +503,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                     if (BIG && !packed)
                         weight = exp((i * i + jj * jj) * wcons);
                     else
-                        weight = etab[ri] * etab[ci];
+                        weight = etab[sm.r] * etab[sm.c];
                     const double mag = grad_mag * weight;
-                    // InterpHistEntry
-                    const double fr_ = floor(ybin), fc_ = floor(xbin), fo_ = floor(obin);
-                    const int r0 = (int)fr_, c0 = (int)fc_, o0 = (int)fo_;
-                    const double d_r = ybin - fr_, d_c = xbin - fc_, d_o = obin - fo_;
+                    // InterpHistEntry: cell indices r1 = r0 + 1, c1 = c0 + 1 in 0..4, fractions by v_fract_f64
+                    const int r1 = (int)ys, c1 = (int)xs, o0 = (int)obin;
+                    const double d_r = __builtin_amdgcn_fract(ys), d_c = __builtin_amdgcn_fract(xs),
+                                 d_o = __builtin_amdgcn_fract(obin);
                     // the eight bins lie at fixed distances from the (r0, c0) cell in the two orientation columns
-                    double *hb = h + (r0 * 4 + c0) * 8;
+                    double *hb = h + (r1 * 4 + c1) * 8 - 40;
                     double *hb0 = hb + (o0 & 7), *hb1 = hb + ((o0 + 1) & 7);
                     const double w_o0 = 1.0 - d_o, w_o1 = d_o;
 #pragma unroll
                     for (int rr = 0; rr <= 1; rr++) {
-                        int rb = r0 + rr;
-                        if (rb >= 0 && rb < 4) {
+                        const unsigned int rb = (unsigned int)(r1 + rr - 1);
+                        if (rb < 4u) {
                             double v_r = mag * ((rr == 0) ? 1.0 - d_r : d_r);
 #pragma unroll
                             for (int cc = 0; cc <= 1; cc++) {
-                                int cb = c0 + cc;
-                                if (cb >= 0 && cb < 4) {
+                                const unsigned int cb = (unsigned int)(c1 + cc - 1);
+                                if (cb < 4u) {
                                     double v_c = v_r * ((cc == 0) ? 1.0 - d_c : d_c);
                                     lds_add(hb0 + (rr * 4 + cc) * 8, v_c * w_o0);
                                     lds_add(hb1 + (rr * 4 + cc) * 8, v_c * w_o1);
@@ -528,6 +529,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                             }
                         }
                     }
+                }
+            };
+            Sample sa, sb;
+            sa.r = sa.c = sb.r = sb.c = 0;
+            sa.nl = sa.nr = sa.nu = sa.nd = sb.nl = sb.nr = sb.nu = sb.nd = (T)0;
+            if (lane < count)
+                fetch(lane, sa);
+            for (int e = lane; e < count; e += 128) {
+                const bool more = e + 64 < count;
+                if (more)
+                    fetch(e + 64, sb);
+                process(sa);
+                if (more) {
+                    if (e + 128 < count)
+                        fetch(e + 128, sa);
+                    process(sb);
                 }
             }
             wave_lds_fence();

@@ -709,6 +709,72 @@ __device__ __forceinline__ void offset3d(const D &g, int l, int x, int y, double
     }
 }
 
+// The 3x3x3 block of DoG values around (level l, x, y), held in registers.  Every quantity of a refinement step --
+// the Hessian, the gradient, the contrast, and the edge test when the level did not move by two -- reads inside this
+// block, so a candidate loads it once per position (36 Gaussian pixels: four levels of 3x3) instead of once per use.
+// Values are formed exactly as Dog3::at forms them (difference in the pyramid's type, then to double).
+template <typename T, bool FROM_DOG>
+struct DogCube {
+    double v[3][3][3]; // [level - l + 1][y' - y + 1][x' - x + 1]
+    __device__ __forceinline__ void load(const OctaveTab &tab, int o, size_t img, int pitch, int l, int x, int y)
+    {
+        constexpr int NG = FROM_DOG ? 3 : 4;
+        T g[NG][3][3];
+#pragma unroll
+        for (int li = 0; li < NG; li++) {
+            const T *p = (const T *)tab.lv[o][l - 1 + li] + img + (size_t)(y - 1) * pitch + (x - 1);
+#pragma unroll
+            for (int yi = 0; yi < 3; yi++)
+#pragma unroll
+                for (int xi = 0; xi < 3; xi++)
+                    g[li][yi][xi] = p[yi * pitch + xi];
+        }
+#pragma unroll
+        for (int li = 0; li < 3; li++)
+#pragma unroll
+            for (int yi = 0; yi < 3; yi++)
+#pragma unroll
+                for (int xi = 0; xi < 3; xi++)
+                    v[li][yi][xi] = FROM_DOG ? (double)g[li][yi][xi] : (double)(T)(g[li + 1 < NG ? li + 1 : li][yi][xi] - g[li][yi][xi]);
+    }
+    // value at (l + dl, x + dx, y + dy), offsets in -1..1 known at compile time
+    __device__ __forceinline__ double at(int dl, int dx, int dy) const { return v[dl + 1][dy + 1][dx + 1]; }
+};
+
+// derivative3d / offset3d on the block's centre: the same expressions in the same order
+template <typename C>
+__device__ __forceinline__ void derivative3d_c(const C &g, double *dx)
+{
+    dx[0] = (g.at(0, 1, 0) - g.at(0, -1, 0)) / 2.0;
+    dx[1] = (g.at(0, 0, 1) - g.at(0, 0, -1)) / 2.0;
+    dx[2] = (g.at(1, 0, 0) - g.at(-1, 0, 0)) / 2.0;
+}
+
+template <typename C>
+__device__ __forceinline__ void offset3d_c(const C &g, double *off)
+{
+    double val = g.at(0, 0, 0);
+    double Dxx = g.at(0, 1, 0) + g.at(0, -1, 0) - 2 * val;
+    double Dyy = g.at(0, 0, 1) + g.at(0, 0, -1) - 2 * val;
+    double Dss = g.at(1, 0, 0) + g.at(-1, 0, 0) - 2 * val;
+    double Dxy = (g.at(0, 1, 1) + g.at(0, -1, -1) - g.at(0, 1, -1) - g.at(0, -1, 1)) / 4.0;
+    double Dxs = (g.at(1, 1, 0) + g.at(-1, -1, 0) - g.at(-1, 1, 0) - g.at(1, -1, 0)) / 4.0;
+    double Dys = (g.at(1, 0, 1) + g.at(-1, 0, -1) - g.at(1, 0, -1) - g.at(-1, 0, 1)) / 4.0;
+    double H[9] = {Dxx, Dxy, Dxs, Dxy, Dyy, Dys, Dxs, Dys, Dss};
+    double Hi[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // stays zero when the Hessian is singular (sift.cpp:778-780)
+    inverse3d(H, Hi);
+    double dx[3];
+    derivative3d_c(g, dx);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double a = 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+            a += Hi[i * 3 + j] * dx[j];
+        off[i] = -a;
+    }
+}
+
 template <typename T, bool FROM_DOG>
 __global__ __launch_bounds__(256) void refine_k(OctaveTab tab, const unsigned int *cand, size_t cand_img,
                                                 const unsigned int *cand_count, KpRec *kp, size_t kp_img,
@@ -745,8 +811,12 @@ __global__ __launch_bounds__(256) void refine_k(OctaveTab tab, const unsigned in
             double off[3] = {0, 0, 0};
             int i = 0;
             bool alive = true;
+            DogCube<T, FROM_DOG> cube;
+            const size_t img_off = (size_t)b * tab.img_stride[o];
+            const int pitch = tab.pitch[o];
+            cube.load(tab, o, img_off, pitch, l, x, y);
             while (i < 5) { // MAX_INTERPOLATION_STEPS
-                offset3d(g, l, x, y, off);
+                offset3d_c(cube, off);
                 if (fabs(off[0]) < 0.5 && fabs(off[1]) < 0.5 && fabs(off[2]) < 0.5)
                     break;
                 // cvRound of an offset far outside int range always fails the range test below
@@ -763,23 +833,40 @@ __global__ __launch_bounds__(256) void refine_k(OctaveTab tab, const unsigned in
                     break;
                 }
                 i++;
+                if (i < 5)
+                    cube.load(tab, o, img_off, pitch, l, x, y); // the block around the new position
             }
             if (alive && i < 5) {
                 double dx[3];
-                derivative3d(g, l, x, y, dx);
+                derivative3d_c(cube, dx);
                 double term = 0.0;
 #pragma unroll
                 for (int q = 0; q < 3; q++)
                     term += dx[q] * off[q];
-                double contrast = fabs(g.at(l, x, y) + 0.5 * term);
+                double contrast = fabs(cube.at(0, 0, 0) + 0.5 * term);
                 if (!(contrast < 0.03 / 3)) { // DXTHRESHOLD / INTERVALS
                     refined = true;
-                    // passEdgeResponse on the ORIGINAL layer at the refined x,y (sift.cpp:960)
-                    double val = g.at(layer, x, y);
-                    double Dxx = g.at(layer, x + 1, y) + g.at(layer, x - 1, y) - 2 * val;
-                    double Dyy = g.at(layer, x, y + 1) + g.at(layer, x, y - 1) - 2 * val;
-                    double Dxy = (g.at(layer, x + 1, y + 1) + g.at(layer, x - 1, y - 1) - g.at(layer, x - 1, y + 1) -
-                                  g.at(layer, x + 1, y - 1)) / 4.0;
+                    // passEdgeResponse on the ORIGINAL layer at the refined x,y (sift.cpp:960): a slice of the block
+                    // unless the level moved by two
+                    double e[3][3]; // [y' - y + 1][x' - x + 1] of level `layer`
+                    const int dl = layer - l;
+                    if (dl >= -1 && dl <= 1) {
+#pragma unroll
+                        for (int yi = 0; yi < 3; yi++)
+#pragma unroll
+                            for (int xi = 0; xi < 3; xi++)
+                                e[yi][xi] = dl == 0 ? cube.v[1][yi][xi] : (dl < 0 ? cube.v[0][yi][xi] : cube.v[2][yi][xi]);
+                    } else {
+#pragma unroll
+                        for (int yi = 0; yi < 3; yi++)
+#pragma unroll
+                            for (int xi = 0; xi < 3; xi++)
+                                e[yi][xi] = g.at(layer, x - 1 + xi, y - 1 + yi);
+                    }
+                    double val = e[1][1];
+                    double Dxx = e[1][2] + e[1][0] - 2 * val;
+                    double Dyy = e[2][1] + e[0][1] - 2 * val;
+                    double Dxy = (e[2][2] + e[0][0] - e[2][0] - e[0][2]) / 4.0;
                     double Tr = Dxx + Dyy;
                     double Det = Dxx * Dyy - Dxy * Dxy;
                     const double r = 10.0; // RATIO

@@ -8,8 +8,8 @@
 // ncclBroadcast calls, rank r the root of slot r.  Over a fully connected xGMI node every slot then crosses each link
 // once.
 //
-// RCCL is bound at run time (dlopen of librccl.so.1, which is the copy a host framework has already loaded, if any):
-// libsiftgpu.so itself has no link-time dependency on it, and a single-GPU caller never touches it.
+// RCCL is bound at run time (dlopen of the librccl that ships beside the HIP runtime in use): libsiftgpu.so itself has
+// no link-time dependency on it, and a single-GPU caller never touches it.
 #include <dlfcn.h>
 #include <stdio.h>
 #include <string.h>
@@ -85,14 +85,24 @@ const Rccl &rccl()
 {
     static const Rccl r = [] {
         Rccl v;
-        // a copy that is already in the process (a host framework's) first, then the system's
-        const char *names[] = {"librccl.so.1", "librccl.so"};
-        for (const char *n : names)
+        // The copy that belongs to the HIP runtime this library is running on: a process may hold more than one ROCm
+        // installation (a host framework ships its own), and an RCCL from one does not work on the runtime of another.
+        // So: the directory of the libamdhip64 that resolved hipGetDeviceCount, by path (DEEPBIND: should another RCCL copy be
+        // in the process already, this one still binds to its own functions); then whatever the loader finds by name.
+        Dl_info info;
+        if (dladdr(reinterpret_cast<void *>(&hipGetDeviceCount), &info) && info.dli_fname) {
+            std::string dir(info.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char *n : {"librccl.so.1", "librccl.so"})
+                    if (!v.lib)
+                        v.lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
+            }
+        }
+        for (const char *n : {"librccl.so.1", "librccl.so"})
             if (!v.lib)
-                v.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-        for (const char *n : names)
-            if (!v.lib)
-                v.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+                v.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
         if (!v.lib) {
             const char *e = dlerror();
             v.why = std::string("RCCL is not available: ") + (e ? e : "dlopen failed");

@@ -72,6 +72,53 @@ __device__ __forceinline__ double sg_atan_split(double mn, double mx, const doub
     return __builtin_fma(u * z, p, u);
 }
 
+// ---- forms for sums of many smooth terms ---------------------------------------------------------------------
+// The descriptor histogram adds about 1 600 weighted samples per feature and every step from a sample to its eight
+// bin weights is continuous, so a relative error of 1e-14 per sample is as good there as 1e-16 (the quantised bins sit
+// 1e-9 and more away from their truncation boundaries); these forms stop one correction step earlier than the
+// 1-ulp ones above.  They are not used where a rounding decision follows directly (orientation bins).
+
+// sqrt(x), x >= 0: v_rsq_f64 seed (about 2^-23 relative) and one coupled Newton-Raphson step: relative error below
+// 3e-14; exactly 0 for x = 0 (the seed of the clamped argument is finite).
+__device__ __forceinline__ double sg_sqrt_sum(double x)
+{
+    const double y = __builtin_amdgcn_rsq(__builtin_fmax(x, 1e-300));
+    const double g = x * y;
+    const double h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    return __builtin_fma(g, r, g);
+}
+
+// n / d, d > 0: v_rcp_f64 seed and one Newton step on the reciprocal: relative error below 3e-14
+__device__ __forceinline__ double sg_div_sum(double n, double d)
+{
+    double r = __builtin_amdgcn_rcp(d);
+    const double e = __builtin_fma(-d, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return n * r;
+}
+
+// sg_atan_split with that division and the odd series cut after u^11/11 (|u| <= tan(pi/32): truncation below 7e-15)
+__device__ __forceinline__ double sg_atan_split_sum(double mn, double mx, const double2 *centres, double &k_term)
+{
+    unsigned int koff = mn > 0.09849140335716425 * mx ? 16u : 0u;
+    koff = mn > 0.30334668360734239 * mx ? 32u : koff;
+    koff = mn > 0.53451113595079158 * mx ? 48u : koff;
+    koff = mn > 0.82067879082866024 * mx ? 64u : koff;
+    const double2 ck = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(centres) + koff);
+    k_term = ck.y;
+    const double num = __builtin_fma(-ck.x, mx, mn);
+    const double den = fmax(__builtin_fma(ck.x, mn, mx), 1e-300);
+    const double u = sg_div_sum(num, den);
+    const double z = u * u;
+    double p = -1.0 / 11.0;
+    p = sg_fma3(p, z, 1.0 / 9.0);
+    p = sg_fma3(p, z, -1.0 / 7.0);
+    p = sg_fma3(p, z, 1.0 / 5.0);
+    p = sg_fma3(p, z, -1.0 / 3.0);
+    return __builtin_fma(u * z, p, u);
+}
+
 // centres[k] = (tan(k*pi/16), k*pi/16) if radians, else (tan(k*pi/16), k/4) -- the angle in units of pi/4 -- for
 // k = 0..4; call with lanes 0..4 at least, then make the stores visible to the readers.
 __device__ __forceinline__ void sg_atan_centres_fill(double2 *centres, int lane, bool radians)

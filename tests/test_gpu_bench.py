@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_small_workload():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "4",
-           "--width", "640", "--height", "480", "--cap", "8192", "--cpu-threads", "2"]
+           "--width", "640", "--height", "480", "--cap", "8192", "--cpu-threads", "2", "--exchange"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
@@ -27,3 +27,9 @@ def test_bench_small_workload():
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 2 and cpu["value"] > 0
     assert line["config"]["batch"] == 4 and "640x480" in line["config"]["workload"]
+    # the untimed extras: every frame of the last batch equals the frame run alone; Sift() through the host layer
+    assert line["batch_check"]["ok"] is True and line["batch_check"]["frames"] == 4
+    assert line["host_api"]["images_per_s"] > 0 and line["host_api"]["sift_ms_single"] > 0
+    # the exchange step ran through the C ABI (a communicator of one rank) and gathered this rank's features unpadded
+    assert "sg_allgather_features" in line["exchange"]
+    assert line["features_gathered_last_step"] == line["features_last_step"] > 0

@@ -179,6 +179,10 @@ int sg_level_dims(const sg_ctx *ctx, int octave, int *rows, int *cols);
 /* Gaussian level (octave, level 0..5) of image `image` of the last call, converted to double */
 int sg_read_level(sg_ctx *ctx, int image, int octave, int level, double *dst);
 int sg_read_counters(sg_ctx *ctx, int image, sg_counters *out);
+/* Work done by the two histogram kernels in the last call, summed over its first n_img images: the number of
+ * 64-sample trips of the descriptor drain loop and of the orientation window walk (one trip = one wave taking 64
+ * window samples).  With the instruction counts of those loops this prices the kernels against the vector issue rate. */
+int sg_read_work_counters(sg_ctx *ctx, int n_img, unsigned long long *descr_trips, unsigned long long *orient_trips);
 /* keypoints after scale assignment and halving, in the reference's emission order */
 int sg_read_keypoints(sg_ctx *ctx, int image, sg_keypoint *out, size_t cap, size_t *n);
 /* features in emission order (before the scale sort) with descriptors; prequant (n x 128, may be NULL)

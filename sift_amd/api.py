@@ -36,7 +36,7 @@ EXPORTS = (
     "sg_downsample", "sg_gaussian_smooth", "sg_create_init_smooth_gray", "sg_gaussian_pyramid", "sg_sub",
     "sg_dog_pyramid", "sg_detect_local_extrema", "sg_calculate_scale", "sg_half_features",
     "sg_orientation_assignment", "sg_descriptor_representation", "sg_sort_features", "sg_last_octaves",
-    "sg_level_dims", "sg_read_level", "sg_read_counters", "sg_read_keypoints", "sg_read_features_unsorted",
+    "sg_level_dims", "sg_read_level", "sg_read_counters", "sg_read_work_counters", "sg_read_keypoints", "sg_read_features_unsorted",
     "sg_set_profiling", "sg_get_stage_times", "sg_reset_stage_times", "sg_malloc", "sg_free", "sg_memcpy_h2d",
     "sg_memcpy_d2h", "sg_synth_vnoise5", "sg_match", "sg_match_packed_device",
     "sg_match_packed_device_noalloc", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy",
@@ -123,6 +123,7 @@ def load_library():
     L.sg_level_dims.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.sg_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     L.sg_read_counters.argtypes = [vp, C.c_int, C.POINTER(Counters)]
+    L.sg_read_work_counters.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong), C.POINTER(C.c_ulonglong)]
     L.sg_read_keypoints.argtypes = [vp, C.c_int, vp, C.c_size_t, szp]
     L.sg_read_features_unsorted.argtypes = [vp, C.c_int, vp, C.c_size_t, szp, dp]
     L.sg_set_profiling.argtypes = [vp, C.c_int]
@@ -430,6 +431,12 @@ class SiftGPU:
         ctr = Counters()
         self._check(self.lib.sg_read_counters(self.ctx, image, C.byref(ctr)))
         return ctr.as_tuple()
+
+    def read_work_counters(self, n_img=1):
+        """(descriptor drain trips, orientation walk trips) of the last call, summed over its first n_img images."""
+        d, o = C.c_ulonglong(0), C.c_ulonglong(0)
+        self._check(self.lib.sg_read_work_counters(self.ctx, n_img, C.byref(d), C.byref(o)))
+        return d.value, o.value
 
     def read_keypoints(self, image=0, cap=1 << 20):
         out = np.zeros(cap, dtype=KEYPOINT_DTYPE)

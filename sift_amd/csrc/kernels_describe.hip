@@ -29,6 +29,21 @@ __device__ __forceinline__ void lds_add(double *p, double v)
     __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// Histogram add in 64-bit fixed point.  The LDS pipe of a compute unit takes a 64-lane ds_add_u64 in half the time
+// of a ds_add_f64, and the descriptor kernel is bound by exactly that pipe.  A bin holds an unsigned count of units of
+// 2^-50: a contribution a*b (below 2, already carrying the factor 2^50) is rounded to a whole unit by one fused
+// multiply-add with 2^52 + 2^51, which leaves the integer in the low 51 bits of the result's bit pattern.  Rounding to
+// 2^-50 is finer than the rounding of a double sum of the same size, and integer adds commute, so a bin no longer
+// depends on the order in which its adds arrive.
+constexpr double kFixScale = 1125899906842624.0;     // 2^50
+constexpr double kFixHalfScale = 33554432.0;         // 2^25: the square root of it, carried by each of two factors
+constexpr double kFixMagic = 6755399441055744.0;     // 2^52 + 2^51
+__device__ __forceinline__ void lds_add_fixed(unsigned long long *p, double a, double b)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(__builtin_fma(a, b, kFixMagic)) & 0x0007ffffffffffffull;
+    __hip_atomic_fetch_add(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 // ---- orientation ---------------------------------------------------------------------------------------
 // One wave (a 64-thread workgroup) per keypoint.  CalculateOrientationHistogram (sift.cpp:1149-1199): the
 // lanes walk the (2r+1)^2 window and add mag*weight into 36-bin LDS histograms with double atomics.  The
@@ -57,7 +72,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_ORI_WPE, 
 orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsigned int *__restrict__ kp_src,
          size_t src_img, const unsigned int *__restrict__ kp_count, double *__restrict__ ori_tmp, size_t ori_img,
          unsigned long long *__restrict__ peak_words, size_t pw_img, unsigned int *__restrict__ chunk_sums,
-         size_t chunks_img, unsigned int cap)
+         size_t chunks_img, unsigned int cap, unsigned long long *__restrict__ counters)
 {
     __shared__ double hist[kOriCopies * kOriCopyStride];
     __shared__ double E[kOriTab];
@@ -82,6 +97,7 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
         rec_next = kpb[ks[j_first]];
     if (j_first + jstep < n)
         slot_next2 = ks[j_first + jstep];
+    unsigned int trips = 0; // 64-sample trips of the window walk, for pricing the kernel against the issue rate
     for (unsigned int j = j_first; j < n; j += jstep) {
         const KpRec r = rec_next;
         if (j + jstep < n)
@@ -102,6 +118,7 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
             const char *gb = reinterpret_cast<const char *>((const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o]);
             const unsigned int pitch_b = (unsigned int)pitch * (unsigned int)sizeof(T);
             const int W = 2 * radius + 1, total = W * W;
+            trips += (unsigned int)((total + 63) >> 6);
             const bool use_tab = !BIG || radius < kOriTab;
             // sample s -> (jj = s / W - radius: y offset; i = s % W - radius: x offset), so that neighbouring lanes
             // read neighbouring pixels (the reference walks x in its outer loop; the sums do not depend on it
@@ -224,6 +241,8 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
         }
         wave_lds_fence(); // the histograms are cleared for the next keypoint
     }
+    if (lane == 0 && trips)
+        atomicAdd(&counters[(size_t)b * 8 + 6], (unsigned long long)trips);
 }
 
 // One-wave workgroups per image for the kernels that walk a list of keypoints or features with a grid-stride loop.
@@ -247,7 +266,8 @@ static unsigned int feature_blocks(unsigned int cap, int B, unsigned int waves_p
 void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
                    size_t src_img_stride, const unsigned int *kp_count, double *ori_tmp, size_t ori_img_stride,
                    unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
-                   size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec, hipStream_t s)
+                   size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec,
+                   unsigned long long *counters, hipStream_t s)
 {
     unsigned int blocks = feature_blocks(cap, B, 64, 256, env().ori_waves);
     if (blocks == 0)
@@ -256,7 +276,7 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
     const bool big = max_radius >= kOriTab;
 #define SG_ORI_LAUNCH(TT, BB)                                                                                         \
     orient_k<TT, BB><<<g, 64, 0, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, kp_count, ori_tmp, ori_img_stride, \
-                                      peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap)
+                                      peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap, counters)
     if (prec == SG_F64) {
         if (big)
             SG_ORI_LAUNCH(double, true);
@@ -277,8 +297,8 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
 // 4x4 grid form, in every window row, one interval of columns; the lanes compute those intervals (one row per
 // lane, a superset by a 1e-6 px margin, clipped to the pixels that have a gradient), the wave then writes the
 // intervals' (row, column) pairs into a queue, and takes the queued samples 64 at a time: the reference's
-// acceptance test in double, gradient, and the trilinear spread into 4x4x8 histograms with LDS double
-// atomics (four copies, lane & 3, at a stride that puts them in different banks; added in a fixed order).
+// acceptance test in double, gradient, and the trilinear spread into 4x4x8 histograms with LDS atomics in 64-bit
+// fixed point (lds_add_fixed; four copies, lane & 3, at a stride that puts them in different banks).
 // So the expensive part runs with full lanes and the window's corners outside the grid are never visited.
 // Against the reference's per-sample formulas three things are algebraically regrouped (results agree to
 // ~1e-15 relative): the rotated coordinates use cos/shw and sin/shw in fused multiply-adds, the window weight
@@ -341,11 +361,12 @@ template <typename T, bool BIG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE, SG_DESCR_WPE))) void descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img,
                                               const unsigned int *__restrict__ feat_count,
                                               uint8_t *__restrict__ desc, size_t desc_img,
-                                              double *__restrict__ prequant, size_t pq_img, unsigned int cap)
+                                              double *__restrict__ prequant, size_t pq_img, unsigned int cap,
+                                              unsigned long long *__restrict__ counters)
 {
-    __shared__ double hist_s[kDescHistPad + kDescCopies * kDescCopyStride];
+    __shared__ unsigned long long hist_s[kDescHistPad + kDescCopies * kDescCopyStride]; // units of 2^-50 (lds_add_fixed)
     __shared__ double etab[BIG ? kDescTab : kDescTabSmall]; // etab[k] = E[|k - radius|], k = row or column in the window
-    double *hist = hist_s + kDescHistPad;
+    unsigned long long *hist = hist_s + kDescHistPad;
     __shared__ unsigned short queue[kDescQueue];
     __shared__ double2 centres[5];
     const int lane = threadIdx.x;
@@ -358,6 +379,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
     FeatRec nxt;
     if (blockIdx.x < n)
         nxt = fr[blockIdx.x];
+    unsigned int trips = 0; // 64-sample trips of the drain loop, for pricing the kernel against the issue rate
     for (unsigned int f = blockIdx.x; f < n; f += gridDim.x) {
         const FeatRec r = nxt;
         if (f + gridDim.x < n)
@@ -385,16 +407,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
 #pragma unroll
         for (int q = 0; q < (kDescCopies * kDescCopyStride + 63) / 64; q++)
             if (lane + 64 * q < kDescCopies * kDescCopyStride)
-                hist[lane + 64 * q] = 0.0;
+                hist[lane + 64 * q] = 0ull;
         {
-            const double e0 = exp((lane * lane) * wcons);
+            const double e0 = exp((lane * lane) * wcons) * kFixHalfScale; // both factors of a weight carry 2^25
             if (lane <= radius && radius + lane < (BIG ? kDescTab : kDescTabSmall)) {
                 etab[radius + lane] = e0;
                 etab[radius - lane] = e0;
             }
             if (BIG && radius >= 64) {
                 const int k2 = lane + 64;
-                const double e1 = exp((k2 * k2) * wcons);
+                const double e1 = exp((k2 * k2) * wcons) * kFixHalfScale;
                 if (k2 <= radius && radius + k2 < kDescTab) {
                     etab[radius + k2] = e1;
                     etab[radius - k2] = e1;
@@ -422,7 +444,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                 }
             }
         }
-        double *h = hist + (lane & (kDescCopies - 1)) * kDescCopyStride;
+        unsigned long long *h = hist + (lane & (kDescCopies - 1)) * kDescCopyStride;
         wave_lds_fence();
 
         int row = 0;
@@ -456,22 +478,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
             }
             // ---- drain: double arithmetic on the listed samples ----
             // The sample list entry and the four neighbour pixels of the lane's next sample are fetched while the
-            // current sample is processed; two sample slots alternate (the loop body is written twice), so that a
-            // fetched sample is used where it landed.
+            // current sample is processed (slots in rotation, see below).
             struct Sample {
-                unsigned int r, c; // row and column inside the window
+                unsigned int rc; // (row << 8) | column inside the window (packed), or the column alone (wide windows)
                 T nl, nr, nu, nd;
             };
             auto fetch = [&](int e, Sample &sm) {
+                unsigned int r, c;
                 if (packed) {
-                    const unsigned int pk = queue[e];
-                    sm.r = pk >> 8;
-                    sm.c = pk & 255u;
+                    sm.rc = queue[e];
+                    r = sm.rc >> 8;
+                    c = sm.rc & 255u;
                 } else {
-                    sm.r = (unsigned int)big_row;
-                    sm.c = (unsigned int)(big_lo + e);
+                    sm.rc = (unsigned int)(big_lo + e);
+                    r = (unsigned int)big_row;
+                    c = sm.rc;
                 }
-                const unsigned int off = ((sm.r + 1u) * (unsigned int)pitch + (sm.c + 1u)) * (unsigned int)sizeof(T);
+                const unsigned int off = ((r + 1u) * (unsigned int)pitch + (c + 1u)) * (unsigned int)sizeof(T);
                 const char *p8 = gb + (size_t)off;
                 sm.nl = *reinterpret_cast<const T *>(p8 - sizeof(T));
                 sm.nr = *reinterpret_cast<const T *>(p8 + sizeof(T));
@@ -479,7 +502,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                 sm.nd = *reinterpret_cast<const T *>(gb_dn + (size_t)off);
             };
             auto process = [&](const Sample &sm) {
-                const int i = (int)sm.r - radius, jj = (int)sm.c - radius;
+                const unsigned int sr = packed ? sm.rc >> 8 : (unsigned int)big_row, sc = packed ? sm.rc & 255u : sm.rc;
+                const int i = (int)sr - radius, jj = (int)sc - radius;
                 const double dx = (double)sm.nr - (double)sm.nl;
                 const double dy = (double)sm.nd - (double)sm.nu;
                 // grid coordinates shifted by one cell (xs = xbin + 1 in (0, 5) for an accepted sample), so that
@@ -501,17 +525,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                     const double obin = obin_c - __builtin_copysign(q, dy);
                     double weight;
                     if (BIG && !packed)
-                        weight = exp((i * i + jj * jj) * wcons);
+                        weight = exp((i * i + jj * jj) * wcons) * kFixScale;
                     else
-                        weight = etab[sm.r] * etab[sm.c];
+                        weight = etab[sr] * etab[sc];
                     const double mag = grad_mag * weight;
                     // InterpHistEntry: cell indices r1 = r0 + 1, c1 = c0 + 1 in 0..4, fractions by v_fract_f64
                     const int r1 = (int)ys, c1 = (int)xs, o0 = (int)obin;
                     const double d_r = __builtin_amdgcn_fract(ys), d_c = __builtin_amdgcn_fract(xs),
                                  d_o = __builtin_amdgcn_fract(obin);
                     // the eight bins lie at fixed distances from the (r0, c0) cell in the two orientation columns
-                    double *hb = h + (r1 * 4 + c1) * 8 - 40;
-                    double *hb0 = hb + (o0 & 7), *hb1 = hb + ((o0 + 1) & 7);
+                    unsigned long long *hb = h + (r1 * 4 + c1) * 8 - 40;
+                    unsigned long long *hb0 = hb + (o0 & 7), *hb1 = hb + ((o0 + 1) & 7);
                     const double w_o0 = 1.0 - d_o, w_o1 = d_o;
 #pragma unroll
                     for (int rr = 0; rr <= 1; rr++) {
@@ -523,40 +547,53 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                                 const unsigned int cb = (unsigned int)(c1 + cc - 1);
                                 if (cb < 4u) {
                                     double v_c = v_r * ((cc == 0) ? 1.0 - d_c : d_c);
-                                    lds_add(hb0 + (rr * 4 + cc) * 8, v_c * w_o0);
-                                    lds_add(hb1 + (rr * 4 + cc) * 8, v_c * w_o1);
+                                    lds_add_fixed(hb0 + (rr * 4 + cc) * 8, v_c, w_o0);
+                                    lds_add_fixed(hb1 + (rr * 4 + cc) * 8, v_c, w_o1);
                                 }
                             }
                         }
                     }
                 }
             };
-            Sample sa, sb;
-            sa.r = sa.c = sb.r = sb.c = 0;
-            sa.nl = sa.nr = sa.nu = sa.nd = sb.nl = sb.nr = sb.nu = sb.nd = (T)0;
+            trips += (unsigned int)((count + 63) >> 6);
+            // Three sample slots in rotation (the loop body is written three times): the loads of a slot are issued two
+            // trips before the slot is used.  One trip of the five resident waves of a SIMD is shorter than a gather's
+            // round trip through the memory system, so a single trip of distance leaves the SIMD waiting.
+            Sample s0, s1, s2;
+            s0.rc = s1.rc = s2.rc = 0;
+            s0.nl = s0.nr = s0.nu = s0.nd = s1.nl = s1.nr = s1.nu = s1.nd = s2.nl = s2.nr = s2.nu = s2.nd = (T)0;
             if (lane < count)
-                fetch(lane, sa);
-            for (int e = lane; e < count; e += 128) {
-                const bool more = e + 64 < count;
-                if (more)
-                    fetch(e + 64, sb);
-                process(sa);
-                if (more) {
-                    if (e + 128 < count)
-                        fetch(e + 128, sa);
-                    process(sb);
+                fetch(lane, s0);
+            if (lane + 64 < count)
+                fetch(lane + 64, s1);
+            for (int e = lane; e < count; e += 192) {
+                if (e + 128 < count)
+                    fetch(e + 128, s2);
+                process(s0);
+                if (e + 64 < count) {
+                    if (e + 192 < count)
+                        fetch(e + 192, s0);
+                    process(s1);
+                    if (e + 128 < count) {
+                        if (e + 256 < count)
+                            fetch(e + 256, s1);
+                        process(s2);
+                    }
                 }
             }
             wave_lds_fence();
         }
 
         // lane L finishes bins 2L and 2L+1
-        double v0 = 0.0, v1 = 0.0;
+        unsigned long long u0 = 0, u1 = 0;
 #pragma unroll
         for (int q2 = 0; q2 < kDescCopies; q2++) {
-            v0 += hist[q2 * kDescCopyStride + 2 * lane];
-            v1 += hist[q2 * kDescCopyStride + 2 * lane + 1];
+            u0 += hist[q2 * kDescCopyStride + 2 * lane];
+            u1 += hist[q2 * kDescCopyStride + 2 * lane + 1];
         }
+        // whole units to double (one rounding: the high word's 2^32 multiples and the low word are both exact)
+        double v0 = __builtin_fma((double)(unsigned int)(u0 >> 32), 4294967296.0, (double)(unsigned int)u0) * (1.0 / kFixScale);
+        double v1 = __builtin_fma((double)(unsigned int)(u1 >> 32), 4294967296.0, (double)(unsigned int)u1) * (1.0 / kFixScale);
         double len_inv = 1.0 / sqrt(wave_sum(v0 * v0 + v1 * v1));
         v0 *= len_inv;
         v1 *= len_inv;
@@ -584,11 +621,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
             (unsigned short)(q0 | (q1 << 8));
         wave_lds_fence(); // the histograms are cleared for the next feature
     }
+    if (lane == 0 && trips)
+        atomicAdd(&counters[(size_t)b * 8 + 5], (unsigned long long)trips);
 }
 
 void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_stride, const unsigned int *feat_count,
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
-                  int max_radius, int B, int prec, hipStream_t s)
+                  int max_radius, int B, int prec, unsigned long long *counters, hipStream_t s)
 {
     unsigned int blocks = feature_blocks(cap, B, 384, 384, env().descr_waves);
     if (blocks == 0)
@@ -597,7 +636,7 @@ void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_str
     const bool big = 2 * max_radius + 1 > kDescTabSmall; // a window row or column beyond the small table
 #define SG_DESCR_LAUNCH(TT, BB)                                                                                       \
     descr_k<TT, BB><<<g, 64, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,         \
-                                     pq_img_stride, cap)
+                                     pq_img_stride, cap, counters)
     if (prec == SG_F64) {
         if (big)
             SG_DESCR_LAUNCH(double, true);

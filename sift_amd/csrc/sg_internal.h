@@ -138,7 +138,8 @@ void launch_refine(const OctaveTab &tab, const unsigned int *cand, size_t cand_i
 void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
                    size_t src_img_stride, const unsigned int *kp_count, double *ori_tmp, size_t ori_img_stride,
                    unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
-                   size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec, hipStream_t s);
+                   size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec,
+                   unsigned long long *counters, hipStream_t s);
 // gathers FeatRec[f] (and fscale[f]) from feat_src -> kp_src -> kp / ori_tmp
 void launch_feat_gather(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src, size_t src_img_stride,
                         const unsigned int *feat_src, size_t fsrc_img_stride, const unsigned int *feat_count,
@@ -147,7 +148,7 @@ void launch_feat_gather(const KpRec *kp, size_t kp_img_stride, const unsigned in
 // max_radius: an upper bound of the features' window radii (selects the kernel variant for very wide windows)
 void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_stride, const unsigned int *feat_count,
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
-                  int max_radius, int B, int prec, hipStream_t s);
+                  int max_radius, int B, int prec, unsigned long long *counters, hipStream_t s);
 // bwork: [B][2][kRankBuckets] scratch, blist: [B][cap] scratch, scratch_totals: [B], overflow_dummy: [1]
 void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
                  size_t rank_img_stride, unsigned int *bwork, unsigned int *blist, unsigned int *scratch_totals,

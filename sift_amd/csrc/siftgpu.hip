@@ -413,7 +413,8 @@ static void orient_phase(sg_ctx *c, const OctaveTab &tab, int B, int max_radius)
     {
         StageScope sc(c, SG_ST_ORIENT);
         launch_orient(tab, c->d_kp, c->cand_cap, c->d_kpsrc, c->feat_cap, n_kp, c->d_ori, (size_t)c->feat_cap * kOriBins,
-                      c->d_pwords, c->pwords_img, ch3, c->chunks_total, c->feat_cap, max_radius, B, c->prm.precision, s);
+                      c->d_pwords, c->pwords_img, ch3, c->chunks_total, c->feat_cap, max_radius, B, c->prm.precision,
+                      c->d_ctr, s);
     }
     {
         StageScope sc(c, SG_ST_COMPACT, 2);
@@ -459,7 +460,7 @@ static void descr_phase(sg_ctx *c, const OctaveTab &tab, int B, int max_radius)
                            (size_t)c->feat_cap * kOriBins, c->d_frec, c->feat_cap, c->d_fscale, c->feat_cap,
                            c->feat_cap, B, s);
         launch_descr(tab, c->d_frec, c->feat_cap, n_feat, c->d_desc, (size_t)c->feat_cap * 128, c->d_pq,
-                     (size_t)c->feat_cap * 128, c->feat_cap, max_radius, B, c->prm.precision, s);
+                     (size_t)c->feat_cap * 128, c->feat_cap, max_radius, B, c->prm.precision, c->d_ctr, s);
     }
 }
 
@@ -1131,6 +1132,26 @@ int sg_read_counters(sg_ctx *c, int image, sg_counters *out)
     HIPCHK(c, hipMemcpyAsync(v, c->d_ctr + 8 * image, sizeof v, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     out->cc00 = v[0]; out->cc0 = v[1]; out->cc1 = v[2]; out->cc2 = v[3]; out->cc3 = v[4];
+    return SG_OK;
+}
+
+int sg_read_work_counters(sg_ctx *c, int n_img, unsigned long long *descr_trips, unsigned long long *orient_trips)
+{
+    if (!c || n_img < 1 || n_img > c->B)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    std::vector<unsigned long long> v((size_t)8 * n_img);
+    HIPCHK(c, hipMemcpyAsync(v.data(), c->d_ctr, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    unsigned long long d = 0, o = 0;
+    for (int i = 0; i < n_img; i++) {
+        d += v[(size_t)8 * i + 5];
+        o += v[(size_t)8 * i + 6];
+    }
+    if (descr_trips)
+        *descr_trips = d;
+    if (orient_trips)
+        *orient_trips = o;
     return SG_OK;
 }
 

@@ -306,7 +306,7 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
 // E[k] = exp(-k^2/(8 shw^2)), and the orientation coordinate is formed directly in bin units and not wrapped
 // into [0, 8) (the bin index wraps).  HistToDescriptor (sift.cpp:1567-1597): normalise, clamp at 0.2, normalise, min(255,(int)(512 v)).
 
-constexpr int kDescQueue = 960;  // queue entries (samples) per round
+constexpr int kDescQueue = 768;  // queue entries (samples) per round: a multiple of 64 (full trips), sized so that 20 waves fit a CU's LDS
 constexpr int kDescCopies = 4;
 constexpr int kDescCopyStride = 130; // doubles; 128 bins + 2, so that the copies start 4 banks apart
 constexpr int kDescTab = 256;      // weight table entries of the wide-window variant (one per window row/column)
@@ -368,12 +368,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
     __shared__ double etab[BIG ? kDescTab : kDescTabSmall]; // etab[k] = E[|k - radius|], k = row or column in the window
     unsigned long long *hist = hist_s + kDescHistPad;
     __shared__ unsigned short queue[kDescQueue];
-    __shared__ double2 centres[5];
+    __shared__ double2 centres[kAtanLutEntries];
     const int lane = threadIdx.x;
     const int b = blockIdx.y;
     const unsigned int n = min(feat_count[b], cap);
     const FeatRec *fr = frec + (size_t)b * frec_img;
-    sg_atan_centres_fill(centres, lane, false);
+    sg_atan_lut_fill(centres, lane);
 
     // the next feature's record is loaded while the current one is processed
     FeatRec nxt;
@@ -511,14 +511,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                 const double xs = __builtin_fma(cs, (double)jj, __builtin_fma(-ss, (double)i, 2.5));
                 const double ys = __builtin_fma(ss, (double)jj, __builtin_fma(cs, (double)i, 2.5));
                 if (xs > 0.0 && xs < 5.0 && ys > 0.0 && ys < 5.0) {
-                    const double grad_mag = sg_sqrt_sum(dx * dx + dy * dy);
+                    const double grad_mag = sg_sqrt_sum(__builtin_fma(dx, dx, dy * dy));
                     // obin = ((pi - atan2(dy,dx)) - ori) * 8/(2 pi) = obin_c - atan2(dy,dx) in units of pi/4; the
                     // histogram index below wraps by itself, so the angle is not brought into [0, 2 pi) first
                     // (obin_c carries +8, which keeps the coordinate positive and leaves the index unchanged)
                     const double ax = fabs(dx), ay = fabs(dy);
                     const double mx = __builtin_fmax(ax, ay), mn = __builtin_fmin(ax, ay);
                     double kq;
-                    const double au = sg_atan_split_sum(mn, mx, centres, kq);
+                    const double au = sg_atan_split_lut(mn, mx, centres, kq);
                     double q = __builtin_fma(au, 4.0 / SG_PI, kq);
                     q = ay > ax ? 2.0 - q : q;
                     q = dx < 0.0 ? 4.0 - q : q;
@@ -537,16 +537,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                     unsigned long long *hb = h + (r1 * 4 + c1) * 8 - 40;
                     unsigned long long *hb0 = hb + (o0 & 7), *hb1 = hb + ((o0 + 1) & 7);
                     const double w_o0 = 1.0 - d_o, w_o1 = d_o;
+                    // mag split over the two rows, each row over the two columns: the far share is a product, the near
+                    // share the remainder
+                    const double v_r1 = mag * d_r, v_r0 = mag - v_r1;
 #pragma unroll
                     for (int rr = 0; rr <= 1; rr++) {
                         const unsigned int rb = (unsigned int)(r1 + rr - 1);
                         if (rb < 4u) {
-                            double v_r = mag * ((rr == 0) ? 1.0 - d_r : d_r);
+                            const double v_r = rr == 0 ? v_r0 : v_r1;
+                            const double v_c1 = v_r * d_c, v_c0 = v_r - v_c1;
 #pragma unroll
                             for (int cc = 0; cc <= 1; cc++) {
                                 const unsigned int cb = (unsigned int)(c1 + cc - 1);
                                 if (cb < 4u) {
-                                    double v_c = v_r * ((cc == 0) ? 1.0 - d_c : d_c);
+                                    const double v_c = cc == 0 ? v_c0 : v_c1;
                                     lds_add_fixed(hb0 + (rr * 4 + cc) * 8, v_c, w_o0);
                                     lds_add_fixed(hb1 + (rr * 4 + cc) * 8, v_c, w_o1);
                                 }
@@ -555,7 +559,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                     }
                 }
             };
-            trips += (unsigned int)((count + 63) >> 6);
             // Three sample slots in rotation (the loop body is written three times): the loads of a slot are issued two
             // trips before the slot is used.  One trip of the five resident waves of a SIMD is shorter than a gather's
             // round trip through the memory system, so a single trip of distance leaves the SIMD waiting.

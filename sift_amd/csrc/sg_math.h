@@ -119,6 +119,43 @@ __device__ __forceinline__ double sg_atan_split_sum(double mn, double mx, const 
     return __builtin_fma(u * z, p, u);
 }
 
+// The same split with the centre picked from a 35-entry table by the single-precision ratio: entry i serves
+// mn/mx in [i/33, (i+1)/33) and holds (tan(k pi/16), k/4) for the k nearest to atan((i + 1/2)/33), so that
+// |u| <= tan(pi/32 + 1/66) = 0.114 and the series' truncation stays below 5e-14.  Two conversions, one v_rcp_f32, two
+// single-precision products and one LDS read replace four double products, four compares and four selects.  A zero
+// gradient (0/0) converts to entry 0 and gives u = 0.
+constexpr int kAtanLutEntries = 35;
+__device__ __forceinline__ void sg_atan_lut_fill(double2 *lut, int lane)
+{
+    if (lane < kAtanLutEntries) {
+        const float mid = ((float)lane + 0.5f) * (1.0f / 33.0f);
+        int k = (int)(atanf(mid) * (16.0f / 3.14159265f) + 0.5f);
+        k = k > 4 ? 4 : k;
+        double2 e;
+        e.x = k == 0 ? 0.0 : k == 1 ? 0.19891236737965800 : k == 2 ? 0.41421356237309503 : k == 3 ? 0.66817863791929888 : 1.0;
+        e.y = 0.25 * k;
+        lut[lane] = e;
+    }
+}
+
+__device__ __forceinline__ double sg_atan_split_lut(double mn, double mx, const double2 *lut, double &k_term)
+{
+    const float t = (float)mn * __builtin_amdgcn_rcpf((float)mx);
+    const unsigned int idx = (unsigned int)(t * 33.0f); // NaN -> 0; a ratio that rounds above 1 -> entry 33
+    const double2 ck = lut[idx < (unsigned int)kAtanLutEntries ? idx : kAtanLutEntries - 1];
+    k_term = ck.y;
+    const double num = __builtin_fma(-ck.x, mx, mn);
+    const double den = fmax(__builtin_fma(ck.x, mn, mx), 1e-300);
+    const double u = sg_div_sum(num, den);
+    const double z = u * u;
+    double p = -1.0 / 11.0;
+    p = sg_fma3(p, z, 1.0 / 9.0);
+    p = sg_fma3(p, z, -1.0 / 7.0);
+    p = sg_fma3(p, z, 1.0 / 5.0);
+    p = sg_fma3(p, z, -1.0 / 3.0);
+    return __builtin_fma(u * z, p, u);
+}
+
 // centres[k] = (tan(k*pi/16), k*pi/16) if radians, else (tan(k*pi/16), k/4) -- the angle in units of pi/4 -- for
 // k = 0..4; call with lanes 0..4 at least, then make the stores visible to the readers.
 __device__ __forceinline__ void sg_atan_centres_fill(double2 *centres, int lane, bool radians)

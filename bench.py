@@ -85,6 +85,40 @@ def measured_traffic(kernel, tname, batch, width, height):
     return None
 
 
+# ns of one SIMD per wave-instruction under full load, measured with profiles/ubench/valu_rate.hip on the MI355X boxes
+# used here (profiles/r02/valu_rate.txt): double-precision arithmetic, conversions and compares 2.1; v_rsq_f64 / v_rcp_f64
+# 7.4; the other vector instructions between 1.1 (VOP1/VOP2 moves and logic) and 1.9 (three-operand integer forms,
+# selects): priced at 1.9.  LDS: ns of a CU's LDS pipe per 64-lane instruction: ds_add_u64 3.5, ds_add_f64 6.8
+# (distinct addresses; same-address lanes serialise), reads 1.8.
+ISSUE_NS = {"valu_f64": 2.1, "transcendental_f64": 7.4, "valu_other": 1.9}
+LDS_NS = {"lds_u64_adds": 3.5, "lds_f64_adds": 6.8, "lds_other": 1.8}
+
+
+def valu_roofline(kernel, trips, kernel_ms, n_simd=1024, n_cu=256):
+    """Prices a histogram kernel against the vector issue rate and the LDS pipe: static instruction counts of its
+    sample loop (profiles/isa_counts.json, from the ISA) x measured 64-sample trips x the measured cost of an
+    instruction, against the kernel's measured time.  The loop's per-feature set-up is not counted, so the fractions
+    are lower bounds."""
+    try:
+        isa = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))[kernel]
+    except (OSError, ValueError, KeyError):
+        return None
+    if not trips or kernel_ms <= 0:
+        return None
+    f64 = isa["valu_f64"] - isa["transcendental_f64"]
+    valu_ns = f64 * ISSUE_NS["valu_f64"] + isa["transcendental_f64"] * ISSUE_NS["transcendental_f64"] + \
+        isa["valu_other"] * ISSUE_NS["valu_other"]
+    adds = isa.get("lds_u64_adds", 0) * LDS_NS["lds_u64_adds"] + isa.get("lds_f64_adds", 0) * LDS_NS["lds_f64_adds"]
+    lds_other = isa["lds"] - isa.get("lds_u64_adds", 0) - isa.get("lds_f64_adds", 0)
+    lds_ns = adds + lds_other * LDS_NS["lds_other"]
+    issue_ms = trips * valu_ns / n_simd * 1e-6
+    lds_ms = trips * lds_ns / n_cu * 1e-6
+    return {"kernel": kernel, "trips_64_samples": int(trips), "kernel_ms": kernel_ms,
+            "valu_instructions_per_trip": isa["valu_f64"] + isa["valu_other"], "valu_f64_per_trip": isa["valu_f64"],
+            "valu_issue_ms": issue_ms, "valu_frac": issue_ms / kernel_ms,
+            "lds_instructions_per_trip": isa["lds"], "lds_pipe_ms": lds_ms, "lds_frac": lds_ms / kernel_ms}
+
+
 def batch_check_and_latency(sift_amd, torch, dev, dev_index, prec, W, H, cap, frames, frame_bytes, first, B, out, counts):
     """Outside the timed region: every frame of the last timed batch run alone (a context of one frame) must give the
     same count and the same packed bytes as it did inside the batch (Sift() is a function of one frame's pixels,
@@ -378,6 +412,7 @@ def main():
             stage_launches[k] = stage_launches.get(k, 0) + ln
         c.set_profiling(False)
     feat_counts = cnts[last_buf[0]].cpu().numpy()
+    work = ctxs[(WU + K - 1) % nctx].read_work_counters(B)  # trips of the histogram loops in the last batch
     gathered_last = gathered_total[last_buf[0]] if do_exchange else None
 
     last_first = ((WU + K - 1) * B) % pool  # first frame of the last step's batch
@@ -511,6 +546,9 @@ def main():
                    "features_per_frame_last_batch": [int(x) for x in feat_counts[:4]]},
         "images_per_sec_per_gpu": value / world,
         "roofline": roofline, "cpu_baseline": cpu_baseline,
+        "valu_roofline": [r for r in (
+            valu_roofline("descr_k<double,false>", work[0], stage_ms.get("descr", 0.0) / K) if esize == 8 else None,
+            valu_roofline("orient_k<double,false>", work[1], stage_ms.get("orient", 0.0) / K) if esize == 8 else None) if r],
         "batch_check": verify, "latency_ms": latency, "host_api": host_api, "exchange": exchange,
         "features_last_step": int(feat_counts.astype(np.int64).sum()), "features_gathered_last_step": gathered_last,
         "stage_ms_per_step": {k: v / K for k, v in stage_ms.items() if v > 0},

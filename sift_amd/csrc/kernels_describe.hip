@@ -177,6 +177,9 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
                         // bin = cvRound(36 (pi - ori) / (2 pi)) (sift.cpp:1190).  The quotient is first taken as a
                         // product with 1/(2 pi), a few ulp from the division; the two can round to different integers
                         // only next to a half-integer, and there the division itself is evaluated.
+                        // (The 1-ulp square root and arctangent stay here although the sums would tolerate less: on a
+                        // mirror-symmetric image neighbouring histogram bins tie exactly, and which side a peak's
+                        // parabola offset falls to then hangs on the last bits.)
                         const double num = kOriBins * (SG_PI - ori);
                         double quo = num * (1.0 / PI2);
                         const bool near_half = fabs(fabs(quo - rint(quo)) - 0.5) < 1e-9;
@@ -562,6 +565,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
             // Three sample slots in rotation (the loop body is written three times): the loads of a slot are issued two
             // trips before the slot is used.  One trip of the five resident waves of a SIMD is shorter than a gather's
             // round trip through the memory system, so a single trip of distance leaves the SIMD waiting.
+            trips += (unsigned int)((count + 63) >> 6);
             Sample s0, s1, s2;
             s0.rc = s1.rc = s2.rc = 0;
             s0.nl = s0.nr = s0.nu = s0.nd = s1.nl = s1.nr = s1.nu = s1.nd = s2.nl = s2.nr = s2.nu = s2.nd = (T)0;

@@ -125,7 +125,7 @@ __device__ __forceinline__ double sg_atan_split_sum(double mn, double mx, const 
 // single-precision products and one LDS read replace four double products, four compares and four selects.  A zero
 // gradient (0/0) converts to entry 0 and gives u = 0.
 constexpr int kAtanLutEntries = 35;
-__device__ __forceinline__ void sg_atan_lut_fill(double2 *lut, int lane)
+__device__ __forceinline__ void sg_atan_lut_fill(double2 *lut, int lane, bool radians = false)
 {
     if (lane < kAtanLutEntries) {
         const float mid = ((float)lane + 0.5f) * (1.0f / 33.0f);
@@ -133,7 +133,7 @@ __device__ __forceinline__ void sg_atan_lut_fill(double2 *lut, int lane)
         k = k > 4 ? 4 : k;
         double2 e;
         e.x = k == 0 ? 0.0 : k == 1 ? 0.19891236737965800 : k == 2 ? 0.41421356237309503 : k == 3 ? 0.66817863791929888 : 1.0;
-        e.y = 0.25 * k;
+        e.y = radians ? 0.19634954084936207 * k : 0.25 * k; // k pi/16, or k/4 in units of pi/4
         lut[lane] = e;
     }
 }
@@ -175,6 +175,21 @@ __device__ __forceinline__ void sg_atan_centres_fill(double2 *centres, int lane,
         e.y = radians ? rad : 0.25 * lane;
         centres[lane] = e;
     }
+}
+
+// atan2(y, x) in radians to about 1e-14, from a table filled by sg_atan_lut_fill(lut, lane, true)
+__device__ __forceinline__ double sg_atan2_lut(double y, double x, const double2 *lut)
+{
+    const double ax = fabs(x), ay = fabs(y);
+    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
+    double off;
+    const double a = sg_atan_split_lut(mn, mx, lut, off);
+    double r = off + a;
+    if (ay > ax)
+        r = 1.5707963267948966 - r;
+    if (x < 0.0)
+        r = 3.1415926535897932 - r;
+    return y < 0.0 ? -r : r;
 }
 
 // atan2(y, x) in radians; centres filled with radians = true.  atan2(0,0) = 0 like the C library.

@@ -862,8 +862,18 @@ void blur_dma_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
             auto read_piece = [&](int step, vec_t *buf) {
                 const int k = step / NPC, c = step % NPC;
 #pragma unroll
-                for (int q = c * CH; q < (c + 1) * CH && q < NWIN; q++)
-                    buf[q - c * CH] = *reinterpret_cast<const vec_t *>(raw + k * ROWE + lane * V + q * V);
+                for (int q = c * CH; q < (c + 1) * CH && q < NWIN; q++) {
+                    // one 16-byte LDS read per vector (volatile, so that it stays one): where the first element of a
+                    // window is not used (A = 1) the compiler otherwise re-pairs the elements into 8-byte-aligned
+                    // ds_read2_b64 accesses, which collide on the banks
+                    typedef T lds_vec_t __attribute__((ext_vector_type(V)));
+                    typedef const volatile __attribute__((address_space(3))) lds_vec_t *lds_vec_ptr; // an LDS pointer, not a flat one
+                    const lds_vec_t t = *(lds_vec_ptr)(raw + k * ROWE + lane * V + q * V);
+                    T *pb = reinterpret_cast<T *>(&buf[q - c * CH]);
+#pragma unroll
+                    for (int e = 0; e < V; e++)
+                        pb[e] = t[e];
+                }
             };
             read_piece(0, rv[0]);
 #pragma unroll

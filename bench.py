@@ -413,6 +413,7 @@ def main():
         c.set_profiling(False)
     feat_counts = cnts[last_buf[0]].cpu().numpy()
     work = ctxs[(WU + K - 1) % nctx].read_work_counters(B)  # trips of the histogram loops in the last batch
+    pair_mask = ctxs[0].last_pair_octaves()  # octaves whose levels 1 and 2 came from one launch
     gathered_last = gathered_total[last_buf[0]] if do_exchange else None
 
     last_first = ((WU + K - 1) * B) % pool  # first frame of the last step's batch
@@ -466,6 +467,8 @@ def main():
             octs = dims[:1] if lvl == 0 else dims
             if fused:
                 octs = [d for d in octs if min(d) > radius_name[lvl]]
+            if fused and lvl in (1, 2):  # octaves whose levels 1 and 2 one launch made are counted under blur_pair
+                octs = [d for o, d in enumerate(dims) if min(d) > radius_name[lvl] and not (pair_mask >> o) & 1]
             nbytes = 2.0 * esize * float(sum(r * c for r, c in octs)) * B * K
             ups = fused and lvl == 0 and blur_mode in ("", "win")
             if ups:  # the base blur reads the double gray plane at input resolution instead of an upsampled plane
@@ -478,6 +481,17 @@ def main():
                              "GBps": nbytes / (ms * 1e-3) / 1e9, "bytes_per_launch_avg": nbytes / max(ln, 1)}
                 tot_bytes += nbytes
                 tot_ms += ms
+    # Levels 1 and 2 of an octave from one launch (blur_pair_k): level 0 read once, both levels written once, i.e.
+    # 3 * sizeof(T) per pixel of the octave and launch (the two single-level launches it replaces move 4).
+    ms, ln = stage_ms.get("blur_pair", 0.0), stage_launches.get("blur_pair", 0)
+    if ms > 0:
+        nbytes = 3.0 * esize * float(sum(r * c for o, (r, c) in enumerate(dims) if (pair_mask >> o) & 1)) * B * K
+        blur["blur_pair"] = {"kernel": "blur_pair_k<%s,R=5+6>" % tname, "taps": 11, "launches": int(ln),
+                             "avg_us": 1e3 * ms / max(ln, 1), "GBps": nbytes / (ms * 1e-3) / 1e9,
+                             "bytes_per_launch_avg": nbytes / max(ln, 1),
+                             "GBps_as_two_launches": nbytes * (4.0 / 3.0) / (ms * 1e-3) / 1e9}
+        tot_bytes += nbytes
+        tot_ms += ms
     # the kernel name the profiler reports merges stage slots that share a template instantiation (R=5: slots 0, 1)
     by_kernel = {}
     for key, d in blur.items():
@@ -515,6 +529,11 @@ def main():
             "launches": e["launches"], "avg_launch_us": 1e3 * e["ms"] / e["launches"],
             "algorithmic_bytes_per_launch": e["bytes"] / e["launches"],
             "all_blur_launches_GBps": (tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else None,
+            # the same launches priced as in a pyramid that blurs level by level (2 * sizeof(T) per pixel and level):
+            # the figure to compare with a run that has no two-level launch
+            "all_blur_GBps_level_by_level_bytes": ((tot_bytes + (blur["blur_pair"]["bytes_per_launch_avg"] *
+                                                    blur["blur_pair"]["launches"] / 3.0 if "blur_pair" in blur else 0.0))
+                                                   / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else None,
         }
 
     cpu_baseline = None

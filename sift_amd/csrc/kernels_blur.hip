@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace sg {
 
@@ -959,6 +960,258 @@ void blur_dma_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
     }
 }
 
+// ---- two consecutive levels in one launch -------------------------------------------------------------------------
+// Levels 1 and 2 of an octave are bound by the memory system (11 and 13 taps), and level 1 is read back only to make
+// level 2.  Here a wave makes both in one walk: the level-1 rows it has just produced go to global memory and, at the
+// same time, into a wave-private LDS row image from which the second row filter takes its lane windows; a second
+// register window holds the row-filtered level-1 rows for the second column filter.  Per pixel the pair then moves
+// one read and two writes (3 x sizeof(T)) instead of two reads and two writes.
+//
+// Geometry.  All stages of a wave work on the same 64*V columns [X0, X0 + TW), lane i on columns X0 + V i ...; the
+// second row filter needs level 1 on RB columns either side of an output, so only the inner PITCH = TW - 2 MG columns
+// of a strip are final (MG >= RB, rounded up so that PITCH columns are whole 128-byte lines): strips advance by PITCH,
+// X0 = strip * PITCH - MG, and both levels are stored for the inner columns only (every pixel of both levels is
+// written once; the 2 MG outer level-1 columns are computed again by the neighbouring strips).  Level-1 columns outside the plane are not blurs of reflected input -- the row filter adds
+// left to right, so that would differ in the last bit from the reference, which reflects level 1 itself -- they are
+// copied inside the LDS image from their mirror columns.  Rows need no such care: the column filter adds the rows
+// above and below in symmetric pairs, so level 1 of a reflected row index, computed from reflected input rows, is
+// bit-identical to level 1 of the mirror row.  A segment starts RA + RB rows early; what the stages produce before
+// their windows have filled is never stored.  Arithmetic and operation order per pixel are those of the
+// single-level kernels.
+// Keeps the compiler from moving LDS accesses across this point.  The hardware needs nothing more between a wave's own
+// LDS writes and its later LDS reads of the same bytes by other lanes: a wave's LDS instructions execute in issue order.
+__device__ __forceinline__ void lds_order() { asm volatile("" ::: "memory"); }
+
+template <typename T, int RA, int RB, int V>
+struct PairGeom {
+    using GA = WinDma<T, RA, V>; // the input ring is that of the single-level kernel
+    static constexpr int TW = 64 * V, KR = 2, LEAD = RA + RB;
+    // columns a strip computes but does not own, either side: at least RB, and such that PITCH columns are whole
+    // 128-byte lines (a strip's stores then never share a line with its neighbour's)
+    static constexpr int MG = (RB * (int)sizeof(T) + 63) / 64 * 64 / (int)sizeof(T);
+    static constexpr int PITCH = TW - 2 * MG;
+    static constexpr int AB = (V - RB % V) % V;
+    static constexpr int NWINB = (AB + 2 * RB + V + V - 1) / V;
+    static constexpr int NPB = 64 + NWINB - 1;
+    static constexpr int ROWB_B = NPB * 16;
+    static constexpr int WAVE_BYTES = GA::WAVE_BYTES + KR * ROWB_B;
+    static_assert(GA::KR == KR, "both stages take two rows per iteration");
+    static_assert(PITCH % V == 0 && MG % V == 0 && MG >= RB && PITCH > 0, "strip starts stay multiples of the vector width");
+};
+
+#ifndef SG_PAIR_WPE
+#define SG_PAIR_WPE 3
+#endif
+template <typename T, int RA, int RB, int V>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_PAIR_WPE, SG_PAIR_WPE)))
+void blur_pair_k(const T *__restrict__ src, T *__restrict__ dst_a, T *__restrict__ dst_b, int rows, int cols, int spitch,
+                 int apitch, int bpitch, size_t simg, size_t aimg, size_t bimg, int seg, Taps<T> taps_a, Taps<T> taps_b)
+{
+    typedef typename VecOf<T, V>::type vec_t;
+    typedef T lds_vec_t __attribute__((ext_vector_type(V)));
+    typedef const volatile __attribute__((address_space(3))) lds_vec_t *lds_vec_ptr;
+    using P = PairGeom<T, RA, RB, V>;
+    using GA = typename P::GA;
+    constexpr int TW = P::TW, KR = P::KR, LEAD = P::LEAD, PITCH = P::PITCH;
+    constexpr int AA = GA::A, NWINA = GA::NWIN, DI = GA::DI, AB = P::AB, NWINB = P::NWINB;
+    constexpr int ROWE_A = GA::ROWB / (int)sizeof(T), ROWE_B = P::ROWB_B / (int)sizeof(T);
+    constexpr int WINA = 2 * RA + KR, WINB = 2 * RB + KR;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int strip = blockIdx.x * 4 + wave;
+    const int own0 = strip * PITCH; // first column this wave stores
+    if (own0 >= cols)
+        return; // the whole wave, before it has requested anything; there is no barrier in this kernel
+    const int own1 = min(own0 + PITCH, cols);
+    const int X0 = own0 - P::MG; // first column the stages compute (negative in the first strip)
+    const int ys = blockIdx.y * seg;
+    const int ye = min(ys + seg, rows);
+    const int xb = X0 + lane * V; // this lane's columns xb .. xb+V-1
+    const bool lane_owns = xb >= own0 && xb < own1;
+    const bool lane_full = lane_owns && xb + V <= own1;
+    const T *s = src + blockIdx.z * simg;
+    T *da = dst_a + blockIdx.z * aimg, *db = dst_b + blockIdx.z * bimg;
+    const int n_iter = (ye - ys + 2 * LEAD + KR - 1) / KR;
+    // stage A: raw input rows in a ring filled by direct-to-LDS loads; element 0 of a row image is column cbase
+    const int cbase = X0 - RA - AA;
+    T *ring = reinterpret_cast<T *>(smem_raw + (size_t)wave * P::WAVE_BYTES);
+    T *img_b = ring + DI * KR * ROWE_A; // KR level-1 row images; element 0 is column X0 - RB - AB
+    const unsigned int lds_wave = (unsigned int)(uintptr_t)smem_raw + (unsigned int)wave * P::WAVE_BYTES;
+    const unsigned int voff0 = (unsigned int)min(max(cbase + V * lane, 0), spitch - V) * (unsigned int)sizeof(T);
+    const unsigned int voff1 = (unsigned int)min(max(cbase + TW + V * lane, 0), spitch - V) * (unsigned int)sizeof(T);
+    const bool left_edge = cbase < 0, right_edge = X0 + TW + RA > cols; // wave-uniform
+    const int e0_a = -cbase;                    // element of input column 0 in a stage-A image (left_edge)
+    const int bbase = X0 - RB - AB;             // column of element 0 of a level-1 image
+    const bool left_b = bbase < 0, right_b = bbase + ROWE_B > cols;
+    auto stage = [&](int t, int slot) {
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const int yy = reflect101_once(ys - LEAD + KR * t + k, rows);
+            const unsigned long long base = (unsigned long long)(uintptr_t)(s + (size_t)yy * spitch);
+            const unsigned int to = lds_wave + (unsigned int)((slot * KR + k) * GA::ROWB);
+            load16_to_lds(to, base, voff0);
+            if (lane < GA::NP - 64)
+                load16_to_lds(to + 1024u, base, voff1);
+        }
+    };
+    // row filter of the lane's V outputs from NW vectors of a row image (tap t of output v = window element A + v + t)
+    auto row_filter = [&](const T *image, auto nw_tag, auto a_tag, auto r_tag, const Taps<T> &taps) -> vec_t {
+        constexpr int NW = decltype(nw_tag)::value, A = decltype(a_tag)::value, R = decltype(r_tag)::value;
+        lds_vec_t rv[NW];
+#pragma unroll
+        for (int q = 0; q < NW; q++)
+            rv[q] = *(lds_vec_ptr)(image + lane * V + q * V);
+        vec_t o;
+        T *po = reinterpret_cast<T *>(&o);
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+#pragma unroll
+            for (int j = 0; j < V; j++) {
+                const int e = q * V + j;
+#pragma unroll
+                for (int vo = 0; vo < V; vo++) {
+                    const int tt = e - vo - A;
+                    if (tt == 0)
+                        po[vo] = taps.k[0] * rv[q][j];
+                    else if (tt > 0 && tt <= 2 * R)
+                        po[vo] = blur_madd(po[vo], taps.k[tt], rv[q][j]);
+                }
+            }
+        }
+        return o;
+    };
+    // column filter on window rows k .. k + 2R (centre R + k)
+    auto col_filter = [&](const vec_t *win, int k, auto r_tag, const Taps<T> &taps) -> vec_t {
+        constexpr int R = decltype(r_tag)::value;
+        vec_t acc;
+        T *pa = reinterpret_cast<T *>(&acc);
+        const T *pc = reinterpret_cast<const T *>(&win[R + k]);
+#pragma unroll
+        for (int e = 0; e < V; e++)
+            pa[e] = taps.k[R] * pc[e];
+#pragma unroll
+        for (int tt = 1; tt <= R; tt++) {
+            const T *pu = reinterpret_cast<const T *>(&win[R + k + tt]);
+            const T *pd = reinterpret_cast<const T *>(&win[R + k - tt]);
+#pragma unroll
+            for (int e = 0; e < V; e++)
+                pa[e] = blur_madd(pa[e], taps.k[R + tt], pu[e] + pd[e]);
+        }
+        return acc;
+    };
+    auto store_row = [&](T *d, int pitch, int y, const vec_t &v) {
+        if (y < ys || y >= ye || !lane_owns)
+            return;
+        T *dr = d + (size_t)y * pitch;
+        if (lane_full) {
+            *reinterpret_cast<vec_t *>(dr + xb) = v;
+        } else {
+            const T *pv = reinterpret_cast<const T *>(&v);
+#pragma unroll
+            for (int e = 0; e < V; e++)
+                if (xb + e < own1)
+                    dr[xb + e] = pv[e];
+        }
+    };
+
+    vec_t win_a[WINA], win_b[WINB];
+#pragma unroll
+    for (int j = 0; j < WINA; j++) {
+        T *pw = reinterpret_cast<T *>(&win_a[j]);
+#pragma unroll
+        for (int e = 0; e < V; e++)
+            pw[e] = (T)0;
+    }
+#pragma unroll
+    for (int j = 0; j < WINB; j++) {
+        T *pw = reinterpret_cast<T *>(&win_b[j]);
+#pragma unroll
+        for (int e = 0; e < V; e++)
+            pw[e] = (T)0;
+    }
+    // the level-1 images start defined: their margins are read (by lanes whose results are dropped) before anything is written there
+    for (int e = lane; e < KR * ROWE_B; e += 64)
+        img_b[e] = (T)0;
+    for (int t = 0; t < min(DI, n_iter); t++)
+        stage(t, t);
+    int slot = 0;
+    for (int t = 0; t < n_iter; t++) {
+        wait_groups_ahead<2 * KR, DI - 1>(n_iter - 1 - t);
+        T *raw = ring + slot * (KR * ROWE_A);
+        if (left_edge) { // input columns -1 .. -RA from their mirrors 1 .. RA
+#pragma unroll
+            for (int k = 0; k < KR; k++)
+                if (lane < RA) {
+                    const T v = raw[k * ROWE_A + e0_a + 1 + lane];
+                    raw[k * ROWE_A + e0_a - 1 - lane] = v;
+                }
+        }
+        if (right_edge) {
+            const int to = cols + lane - cbase, from = cols - 2 - lane - cbase;
+#pragma unroll
+            for (int k = 0; k < KR; k++)
+                if (lane < RA && to < ROWE_A) {
+                    const T v = raw[k * ROWE_A + from];
+                    raw[k * ROWE_A + to] = v;
+                }
+        }
+        lds_order(); // LDS operations of a wave execute in issue order: the copies above are seen by the reads below
+        // ---- stage A: row filter of the two input rows, column filter -> two level-1 rows ----
+#pragma unroll
+        for (int j = 0; j + KR < WINA; j++)
+            win_a[j] = win_a[j + KR];
+#pragma unroll
+        for (int k = 0; k < KR; k++)
+            win_a[2 * RA + k] = row_filter(raw + k * ROWE_A, std::integral_constant<int, NWINA>{},
+                                           std::integral_constant<int, AA>{}, std::integral_constant<int, RA>{}, taps_a);
+        wait_lgkm0(); // the slot's reads have returned: it is loaded again
+        if (t + DI < n_iter)
+            stage(t + DI, slot);
+        slot = slot + 1 == DI ? 0 : slot + 1;
+        const int y1 = ys - LEAD - RA + KR * t; // level-1 row of k = 0 (a reflected index outside the plane)
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const vec_t a = col_filter(win_a, k, std::integral_constant<int, RA>{}, taps_a);
+            store_row(da, apitch, y1 + k, a);
+            *reinterpret_cast<vec_t *>(img_b + k * ROWE_B + RB + AB + lane * V) = a;
+        }
+        lds_order(); // the other lanes' level-1 values are read below; in-order LDS needs no wait for that
+        if (left_b) { // level-1 columns -1 .. -RB from their mirrors 1 .. RB
+#pragma unroll
+            for (int k = 0; k < KR; k++)
+                if (lane < RB) {
+                    const T v = img_b[k * ROWE_B - bbase + 1 + lane];
+                    img_b[k * ROWE_B - bbase - 1 - lane] = v;
+                }
+        }
+        if (right_b) { // level-1 columns cols .. cols+RB-1 from cols-2 .. cols-1-RB
+            const int to = cols + lane - bbase, from = cols - 2 - lane - bbase;
+#pragma unroll
+            for (int k = 0; k < KR; k++)
+                if (lane < RB && to < ROWE_B && from >= 0) {
+                    const T v = img_b[k * ROWE_B + from];
+                    img_b[k * ROWE_B + to] = v;
+                }
+        }
+        lds_order();
+        // ---- stage B: row filter of the two level-1 rows, column filter -> two level-2 rows ----
+#pragma unroll
+        for (int j = 0; j + KR < WINB; j++)
+            win_b[j] = win_b[j + KR];
+#pragma unroll
+        for (int k = 0; k < KR; k++)
+            win_b[2 * RB + k] = row_filter(img_b + k * ROWE_B, std::integral_constant<int, NWINB>{},
+                                           std::integral_constant<int, AB>{}, std::integral_constant<int, RB>{}, taps_b);
+        lds_order(); // the images are rewritten in the next iteration, after these reads in issue order
+        const int y2 = y1 - RB;
+#pragma unroll
+        for (int k = 0; k < KR; k++) {
+            const vec_t b = col_filter(win_b, k, std::integral_constant<int, RB>{}, taps_b);
+            store_row(db, bpitch, y2 + k, b);
+        }
+    }
+}
+
 // true when blur_dma_k applies: 16-byte aligned rows (SIFTGPU_BLUR_DIRECT=1 keeps the register form everywhere)
 template <typename T, int V>
 static bool blur_dma_ok(const Plane &src)
@@ -1309,6 +1562,43 @@ bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *
     if (prec == SG_F64)
         return fused_dispatch<double, 2>(src, dst, B, taps, n, dec, s);
     return fused_dispatch<float, 4>(src, dst, B, taps, n, dec, s);
+}
+
+// Levels a and b = blur(a) of one plane in one launch (blur_pair_k): for the 11- and 13-tap pair of the pyramid's
+// levels 1 and 2, rows staged by LDS-DMA, and launches whose segments are long enough that the RA + RB rows a segment
+// starts early do not matter.  False (nothing launched) otherwise: the caller then blurs level by level.
+template <typename T, int V>
+static bool pair_dispatch(const Plane &src, const Plane &dst_a, const Plane &dst_b, int B, const double *taps_a, int n_a,
+                          const double *taps_b, int n_b, hipStream_t s)
+{
+    constexpr int RA = 5, RB = 6;
+    using P = PairGeom<T, RA, RB, V>;
+    if (!env().blur_pair || env().blur_mode != 0 || n_a <= 1 || n_b <= 1 || bucket_radius(n_a / 2) != RA ||
+        bucket_radius(n_b / 2) != RB)
+        return false;
+    const int rows = src.rows, cols = src.cols;
+    if (rows < 4 * P::LEAD || cols < 4 * P::LEAD || !blur_dma_ok<T, V>(src) || dst_a.pitch % V || dst_b.pitch % V ||
+        (uintptr_t)dst_a.p % 16 || (uintptr_t)dst_b.p % 16 || (dst_a.img_stride * sizeof(T)) % 16 ||
+        (dst_b.img_stride * sizeof(T)) % 16)
+        return false;
+    const int strips = (cols + P::PITCH - 1) / P::PITCH;
+    const int seg = win_segment_rows(rows, (long long)strips * B, P::LEAD, SG_PAIR_WPE);
+    if (seg < 8 * P::LEAD && seg < rows && env().blur_pair != 2)
+        return false; // short segments: the early rows would be a large share of the work
+    const int nseg = (rows + seg - 1) / seg;
+    dim3 g((strips + 3) / 4, nseg, B);
+    blur_pair_k<T, RA, RB, V><<<g, 256, 4 * P::WAVE_BYTES, s>>>(
+        (const T *)src.p, (T *)dst_a.p, (T *)dst_b.p, rows, cols, src.pitch, dst_a.pitch, dst_b.pitch, src.img_stride,
+        dst_a.img_stride, dst_b.img_stride, seg, padded_taps<T>(taps_a, n_a, RA), padded_taps<T>(taps_b, n_b, RB));
+    return true;
+}
+
+bool launch_blur_pair(const Plane &src, const Plane &dst_a, const Plane &dst_b, int B, const double *taps_a, int n_a,
+                      const double *taps_b, int n_b, int prec, hipStream_t s)
+{
+    if (prec == SG_F64)
+        return pair_dispatch<double, 2>(src, dst_a, dst_b, B, taps_a, n_a, taps_b, n_b, s);
+    return pair_dispatch<float, 4>(src, dst_a, dst_b, B, taps_a, n_a, taps_b, n_b, s);
 }
 
 bool blur_fused_decimates(const Plane &src, int n, int prec)

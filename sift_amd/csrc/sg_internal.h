@@ -23,11 +23,15 @@ constexpr int kRankBuckets = 16384; // 16 binades x 1024 mantissa steps of the s
 // Debug / comparison switches, read from the environment once per process (first sg_create) and never on a launch path:
 //   SIFTGPU_BLUR=2pass|ring|win   blur variant (default: the register-window kernels with LDS-DMA staging)
 //   SIFTGPU_BLUR_DIRECT=1         input rows loaded by the lanes instead of LDS-DMA
+//   SIFTGPU_BLUR_PAIR=0|2         pyramid levels 1 and 2 always as two launches | as one wherever the plane allows
+//                                 (default: one launch where a wave's row segment is long)
 //   SIFTGPU_DETECT_DIRECT=1       detect rows loaded into registers instead of LDS-DMA
 //   SIFTGPU_ORI_WAVES / SIFTGPU_DESCR_WAVES   total waves of the orientation / descriptor launches
 struct Env {
     int blur_mode = 0; // 0 default, 1 "2pass", 2 "ring", 3 "win"
     bool blur_direct = false, detect_direct = false;
+    int blur_pair = 1; // SIFTGPU_BLUR_PAIR: 0 levels 1 and 2 always as two launches, 1 one launch where segments are
+                       // long (default), 2 one launch wherever the plane is large enough (tests)
     int ori_waves = 0, descr_waves = 0; // 0 = library default
     int n_cu = 256;                     // compute units of the current device at first use
 };
@@ -112,6 +116,10 @@ bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *
 // apply (the caller then upsamples into a plane and blurs that).
 bool launch_blur_fused_upsampled(const Plane &gray, const Plane &dst, int B, const double *taps, int n, int prec,
                                  hipStream_t s);
+// dst_a = blur(src, taps_a) and dst_b = blur(dst_a, taps_b) in one launch; false (nothing launched) where that form
+// does not apply (the caller then runs the two blurs one after the other)
+bool launch_blur_pair(const Plane &src, const Plane &dst_a, const Plane &dst_b, int B, const double *taps_a, int n_a,
+                      const double *taps_b, int n_b, int prec, hipStream_t s);
 // true when launch_blur_fused can also write the 2:1 decimated copy of its output (DownSample) into `dec`
 bool blur_fused_decimates(const Plane &src, int n, int prec);
 

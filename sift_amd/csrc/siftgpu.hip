@@ -30,6 +30,8 @@ const Env &env()
             v.blur_mode = strcmp(b, "2pass") == 0 ? 1 : strcmp(b, "ring") == 0 ? 2 : strcmp(b, "win") == 0 ? 3 : 0;
         v.blur_direct = getenv("SIFTGPU_BLUR_DIRECT") != nullptr;
         v.detect_direct = getenv("SIFTGPU_DETECT_DIRECT") != nullptr;
+        if (const char *pr = getenv("SIFTGPU_BLUR_PAIR"))
+            v.blur_pair = strcmp(pr, "0") == 0 ? 0 : (strcmp(pr, "2") == 0 ? 2 : 1);
         if (const char *w = getenv("SIFTGPU_ORI_WAVES"))
             v.ori_waves = atoi(w);
         if (const char *w = getenv("SIFTGPU_DESCR_WAVES"))
@@ -164,6 +166,7 @@ struct sg_ctx {
     unsigned int *d_outcounts = nullptr;
 
     bool prof = false;
+    unsigned int pair_octaves = 0; // octaves of the last call whose levels 1 and 2 came from one launch
     bool launch_failed = false; // a blur could not be launched (its taps found no device memory)
     bool fused_blur = true; // one-launch blur; SIFTGPU_BLUR=2pass selects the separate row/column kernels
     StageEvents ev;
@@ -285,7 +288,7 @@ static void flush_events(sg_ctx *c)
     (void)hipStreamSynchronize(c->stream);
     for (int i = 0; i < c->ev.used; i++) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, c->ev.start[i], c->ev.stop[i]) == hipSuccess) {
+        if (c->ev.stage[i] >= 0 && hipEventElapsedTime(&ms, c->ev.start[i], c->ev.stop[i]) == hipSuccess) {
             c->stage_ms[c->ev.stage[i]] += ms;
         }
     }
@@ -294,8 +297,8 @@ static void flush_events(sg_ctx *c)
 
 struct StageScope {
     sg_ctx *c;
-    int idx = -1;
-    StageScope(sg_ctx *ctx, int stage, int launches = 1) : c(ctx)
+    int idx = -1, n = 0;
+    StageScope(sg_ctx *ctx, int stage, int launches = 1) : c(ctx), n(launches)
     {
         if (!c->prof)
             return;
@@ -305,6 +308,18 @@ struct StageScope {
         c->ev.stage[idx] = stage;
         c->stage_launches[stage] += launches;
         (void)hipEventRecord(c->ev.start[idx], c->stream);
+    }
+    // nothing was launched under this scope: its event pair and launch count are handed back
+    void cancel()
+    {
+        if (idx < 0)
+            return;
+        c->stage_launches[c->ev.stage[idx]] -= n;
+        if (idx == c->ev.used - 1)
+            c->ev.used--; // (the start event was recorded; an unused recorded event is harmless)
+        else
+            c->ev.stage[idx] = -1;
+        idx = -1;
     }
     ~StageScope()
     {
@@ -563,6 +578,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
     }
     bool have_base = true; // level 0 of the octave is in place
     bool forked = false;
+    c->pair_octaves = 0;
     for (int o = 0; o < c->octaves; o++) {
         if (!have_base) {
             StageScope sc(c, SG_ST_DOWNSAMPLE);
@@ -582,6 +598,16 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
                              blur_fused_supported(c->level[o][3], c->ntaps[4]) &&
                              blur_fused_supported(c->level[o][4], c->ntaps[5]);
         for (int l = 1; l < kLevels; l++) {
+            if (l == 1 && c->fused_blur) { // levels 1 and 2 in one launch where that form applies
+                StageScope sc(c, SG_ST_BLUR_PAIR);
+                if (launch_blur_pair(c->level[o][0], c->level[o][1], c->level[o][2], B, c->taps[1], c->ntaps[1], c->taps[2],
+                                     c->ntaps[2], prec, s)) {
+                    c->pair_octaves |= 1u << o;
+                    l = 2;
+                    continue;
+                }
+                sc.cancel();
+            }
             // the blur that produces level 3 also writes the next octave's level 0 (its 2:1 decimation) when it can
             const bool want_dec = l == 3 && o + 1 < c->octaves && c->rows[o + 1] != c->rows[o];
             if (l == 4 && side_ok) {
@@ -1088,6 +1114,8 @@ int sg_extract(sg_ctx *c, const uint8_t *px, int width, int height, int channels
 // ---- inspection -------------------------------------------------------------------------------------------
 
 int sg_last_octaves(const sg_ctx *c) { return c ? c->octaves : 0; }
+
+unsigned int sg_last_pair_octaves(const sg_ctx *c) { return c ? c->pair_octaves : 0; }
 
 int sg_level_dims(const sg_ctx *c, int octave, int *rows, int *cols)
 {

@@ -377,3 +377,35 @@ def test_one_pixel_dimension_is_rejected(oracle, gpu64):
         gpu64.extract(oracle.vnoise5(1, 1, 3))
     with pytest.raises(sift_amd.SiftGpuError):
         gpu64.extract(oracle.vnoise5(40, 1, 3))
+
+
+def test_pair_blur_forced_on_small_and_ragged_planes():
+    """Levels 1 and 2 from one launch (blur_pair_k) wherever the plane allows, short segments included: the pyramid
+    must stay bit-equal to the oracle's, borders, odd widths and batches included.  Run in a process of its own because
+    the switch is read once per process."""
+    import subprocess
+    import sys
+    code = r'''
+import numpy as np, sift_amd
+from oracle import oracle as O
+for (w, h, seed) in [(200, 150, 3), (333, 211, 4), (64, 48, 5), (117, 116, 6), (640, 480, 7)]:
+    img = sift_amd.vnoise5(w, h, seed)
+    dbg = O.Debug(img)
+    with sift_amd.SiftGPU(max_width=w, max_height=h, max_batch=2) as c:
+        got = c.extract(img)
+        assert c.last_pair_octaves() & 1, (w, h)
+        for o in range(dbg.octaves):
+            for l in range(6):
+                assert np.array_equal(c.read_level(o, l), dbg.gauss[o * 6 + l]), (w, h, o, l)
+        assert c.read_counters() == dbg.counters
+        ref, _, _, _ = O.sift(img)
+        assert len(got) == len(ref) and np.array_equal(got["descriptor"], ref["descriptor"])
+        two = c.extract_batch(np.stack([img, img[::-1].copy()]), 8192)
+        assert np.array_equal(two[0]["desc"], ref["descriptor"].astype(np.uint8))
+print("pair ok")
+'''
+    import os
+    env = dict(os.environ, SIFTGPU_BLUR_PAIR="2")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0 and "pair ok" in r.stdout, r.stderr[-3000:] + r.stdout[-500:]

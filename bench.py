@@ -187,7 +187,7 @@ def host_api_throughput(W, H, dev_index, cpu_threads):
         return {"error": "%s is not built" % exe}
     threads = cpu_threads or min(16, os.cpu_count() or 1)
     try:
-        p = subprocess.run([exe, str(W), str(H), str(threads), "12", str(dev_index)], capture_output=True, text=True,
+        p = subprocess.run([exe, str(W), str(H), str(threads), "20", str(dev_index)], capture_output=True, text=True,
                            timeout=240)
         if p.returncode != 0:
             return {"error": p.stderr.strip()[-300:]}

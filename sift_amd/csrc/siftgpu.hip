@@ -158,6 +158,8 @@ struct sg_ctx {
     unsigned int last_ov[4] = {0, 0, 0, 0}; // the counts of the last reported overflow (sg_required_features)
     void *d_out = nullptr;
     // pinned staging for large downloads into pageable caller memory: two halves, filled and emptied alternately
+    unsigned char *h_in = nullptr; // pinned staging of the single-image entry points' input
+    size_t h_in_bytes = 0;
     unsigned char *h_stage = nullptr;
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     size_t pending_features = 0; // feature count of the last sg_extract_begin, not fetched yet
@@ -667,6 +669,25 @@ static int ensure_in(sg_ctx *c, size_t bytes)
     return SG_OK;
 }
 
+static int ensure_pinned_in(sg_ctx *c, size_t bytes)
+{
+    if (bytes <= c->h_in_bytes)
+        return SG_OK;
+    if (c->h_in) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipHostFree(c->h_in);
+    }
+    c->h_in = nullptr;
+    c->h_in_bytes = 0;
+    if (hipHostMalloc((void **)&c->h_in, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        c->h_in = nullptr;
+        return SG_E_NOMEM;
+    }
+    c->h_in_bytes = bytes;
+    return SG_OK;
+}
+
 static int ensure_out(sg_ctx *c, size_t bytes)
 {
     if (bytes <= c->out_bytes)
@@ -803,6 +824,8 @@ int sg_destroy(sg_ctx *c)
             (void)hipFree(b);
     if (c->h_stage)
         (void)hipHostFree(c->h_stage);
+    if (c->h_in)
+        (void)hipHostFree(c->h_in);
     for (hipEvent_t e : c->stage_ev)
         if (e)
             (void)hipEventDestroy(e);
@@ -1063,7 +1086,16 @@ int sg_extract_begin(sg_ctx *c, const uint8_t *px, int width, int height, int ch
     int rc = ensure_in(c, img_bytes);
     if (rc != SG_OK)
         return rc;
-    HIPCHK(c, hipMemcpyAsync(c->d_in, px, image_bytes(width, height, channels, stride), hipMemcpyHostToDevice, c->stream));
+    {
+        // The caller's image is pageable as a rule: it goes through a pinned buffer of the context, so that the
+        // transfer itself is one asynchronous DMA (a pageable source makes the runtime stage the copy under its own lock,
+        // which serialises host threads that each drive a context).
+        const size_t nbytes = image_bytes(width, height, channels, stride);
+        const bool pinned = ensure_pinned_in(c, nbytes) == SG_OK;
+        if (pinned)
+            memcpy(c->h_in, px, nbytes);
+        HIPCHK(c, hipMemcpyAsync(c->d_in, pinned ? c->h_in : px, nbytes, hipMemcpyHostToDevice, c->stream));
+    }
     rc = run_pipeline(c, c->d_in, 1, width, height, channels, stride, img_bytes);
     if (rc != SG_OK)
         return rc;

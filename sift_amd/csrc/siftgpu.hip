@@ -103,7 +103,7 @@ struct StageEvents {
 } // namespace
 
 // octaves of at most this many pixels per level (all frames of the batch together) blur levels 4 and 5 on the side stream
-constexpr size_t kSideStreamPixels = 4u << 20;
+constexpr size_t kSideStreamPixels = 16u << 20;
 
 struct sg_ctx {
     sg_params prm;

@@ -120,6 +120,32 @@ int sg_extract(sg_ctx *ctx, const uint8_t *px, int width, int height, int channe
 int sg_extract_begin(sg_ctx *ctx, const uint8_t *px, int width, int height, int channels, size_t stride, size_t *n);
 int sg_extract_fetch(sg_ctx *ctx, sg_keypoint *out, size_t cap, size_t *n);
 
+/* A feature on its way to a sg_keypoint record: every field of the record, the descriptor as the 128 bytes it is
+ * (the record's 128 doubles hold integers 0..255).  224 bytes instead of 1120: what crosses the bus. */
+typedef struct sg_wire_feature {
+    int32_t octave, interval, x, y;
+    double offset_interval, scale, dx, dy, offset_x, offset_y, octave_scale, ori, val;
+    double reserved;
+    uint8_t desc[128];
+} sg_wire_feature;
+
+/* Several host images of one size through the path in one batch, for a host layer that serves Sift() calls of
+ * several threads with one context (n_img <= sg_params.max_batch).  sg_extract_batch_begin uploads and runs the
+ * path; counts[i] receives the number of features of image i.  `pinned` != 0 promises that every image lies in
+ * page-locked memory (sg_host_alloc): the uploads are then direct DMA transfers; otherwise each image goes through
+ * a page-locked buffer of the context.  sg_extract_batch_fetch_wire then writes the records of all images back to
+ * back (image 0 first; image i starts at the sum of the counts before it) as sg_wire_feature, ordered per image
+ * like sg_extract's; out should be page-locked too.  sg_expand_wire is the CPU step from those to reference-layout
+ * records (any thread, no context).  Capacity overflow of an internal buffer: SG_E_CAPACITY from
+ * sg_extract_batch_begin (see sg_required_features). */
+int sg_extract_batch_begin(sg_ctx *ctx, const uint8_t *const *imgs, int n_img, int width, int height, int channels,
+                           size_t stride, int pinned, uint32_t *counts);
+int sg_extract_batch_fetch_wire(sg_ctx *ctx, sg_wire_feature *out, size_t cap_total);
+void sg_expand_wire(const sg_wire_feature *in, size_t n, sg_keypoint *out);
+/* Page-locked host memory for the two calls above (hipHostMalloc / hipHostFree). */
+int sg_host_alloc(size_t bytes, void **ptr);
+int sg_host_free(void *ptr);
+
 /* Throughput form of the same path: n_img device-resident images of one size (image i starts at
  * d_imgs + i*img_stride), packed features written to d_out + i*cap_per_image, counts to d_counts[i].
  * Asynchronous on the context's stream; sg_sync() waits and reports capacity overflow. */

@@ -26,13 +26,21 @@ KEYPOINT_DTYPE = np.dtype({
     "itemsize": 1120,
 })
 
+# sg_wire_feature: a Keypoint record with its descriptor as bytes, 224 bytes.
+WIRE_DTYPE = np.dtype([("octave", "<i4"), ("interval", "<i4"), ("x", "<i4"), ("y", "<i4"), ("offset_interval", "<f8"),
+                       ("scale", "<f8"), ("dx", "<f8"), ("dy", "<f8"), ("offset_x", "<f8"), ("offset_y", "<f8"),
+                       ("octave_scale", "<f8"), ("ori", "<f8"), ("val", "<f8"), ("reserved", "<f8"),
+                       ("desc", "u1", (128,))])
+assert WIRE_DTYPE.itemsize == 224
+
 PACKED_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("scale", "<f4"), ("ori", "<f4"), ("desc", "u1", (128,))])
 assert PACKED_DTYPE.itemsize == 144
 
 # Every symbol include/siftgpu.h declares.
 EXPORTS = (
     "sg_default_params", "sg_strerror", "sg_last_error", "sg_device_count", "sg_create", "sg_destroy", "sg_sync", "sg_required_features",
-    "sg_extract", "sg_extract_begin", "sg_extract_fetch", "sg_extract_batch_device", "sg_extract_batch", "sg_convert_to_gray", "sg_upsample",
+    "sg_extract", "sg_extract_begin", "sg_extract_fetch", "sg_extract_batch_begin", "sg_extract_batch_fetch_wire",
+    "sg_expand_wire", "sg_host_alloc", "sg_host_free", "sg_extract_batch_device", "sg_extract_batch", "sg_convert_to_gray", "sg_upsample",
     "sg_downsample", "sg_gaussian_smooth", "sg_create_init_smooth_gray", "sg_gaussian_pyramid", "sg_sub",
     "sg_dog_pyramid", "sg_detect_local_extrema", "sg_calculate_scale", "sg_half_features",
     "sg_orientation_assignment", "sg_descriptor_representation", "sg_sort_features", "sg_last_octaves",
@@ -92,6 +100,13 @@ def load_library():
     L.sg_extract.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_size_t, vp, C.c_size_t, szp]
     L.sg_extract_begin.argtypes = [vp, u8p, C.c_int, C.c_int, C.c_int, C.c_size_t, szp]
     L.sg_extract_fetch.argtypes = [vp, vp, C.c_size_t, szp]
+    L.sg_extract_batch_begin.argtypes = [vp, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
+                                         C.POINTER(C.c_uint32)]
+    L.sg_extract_batch_fetch_wire.argtypes = [vp, vp, C.c_size_t]
+    L.sg_expand_wire.argtypes = [vp, C.c_size_t, vp]
+    L.sg_expand_wire.restype = None
+    L.sg_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
+    L.sg_host_free.argtypes = [vp]
     L.sg_extract_batch_device.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_size_t, vp,
                                           C.c_size_t, vp]
     L.sg_extract_batch.argtypes = [vp, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, vp,
@@ -229,6 +244,37 @@ class SiftGPU:
         rc = self.lib.sg_extract_batch(self.ctx, ptrs, n, w, h, ch, w * ch, out.ctypes.data, cap_per_image, counts)
         self._check(rc)
         return [out[i, : counts[i]].copy() for i in range(n)]
+
+    def extract_batch_wire(self, imgs, pinned=False):
+        """Several host images of one size in one batch -> list of KEYPOINT_DTYPE arrays (sg_extract_batch_begin,
+        sg_extract_batch_fetch_wire, sg_expand_wire).  pinned: stage images and records in page-locked memory."""
+        imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
+        n, h, w, ch = imgs.shape
+        ptrs = (C.POINTER(C.c_uint8) * n)()
+        host_in = C.c_void_p()
+        if pinned:
+            rc = self.lib.sg_host_alloc(imgs.nbytes, C.byref(host_in))
+            if rc != SG_OK:
+                raise SiftGpuError(rc, "sg_host_alloc")
+            C.memmove(host_in, imgs.ctypes.data, imgs.nbytes)
+        try:
+            for i in range(n):
+                ptrs[i] = (C.cast(host_in.value + i * imgs[0].nbytes, C.POINTER(C.c_uint8)) if pinned else _u8(imgs[i]))
+            counts = (C.c_uint32 * n)()
+            self._check(self.lib.sg_extract_batch_begin(self.ctx, ptrs, n, w, h, ch, w * ch, int(pinned), counts))
+        finally:
+            if pinned:
+                self.lib.sg_host_free(host_in)
+        total = sum(counts)
+        wire = np.zeros(max(total, 1), dtype=WIRE_DTYPE)
+        self._check(self.lib.sg_extract_batch_fetch_wire(self.ctx, wire.ctypes.data, total))
+        recs = np.zeros(max(total, 1), dtype=KEYPOINT_DTYPE)
+        self.lib.sg_expand_wire(wire.ctypes.data, total, recs.ctypes.data)
+        out, at = [], 0
+        for i in range(n):
+            out.append(recs[at: at + counts[i]].copy())
+            at += counts[i]
+        return out
 
     def extract_batch_device(self, d_imgs, n_img, w, h, ch, d_out, cap_per_image, d_counts):
         """Device-pointer form (ints); asynchronous. Call sync() before reading the outputs."""

@@ -164,6 +164,7 @@ struct sg_ctx {
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     size_t pending_features = 0; // feature count of the last sg_extract_begin, not fetched yet
     bool have_pending = false;
+    std::vector<uint32_t> pending_counts; // per image, of the last sg_extract_batch_begin (empty: none pending)
     size_t out_bytes = 0;
     unsigned int *d_outcounts = nullptr;
 
@@ -720,6 +721,12 @@ static int ensure_stage(sg_ctx *c)
     return SG_OK;
 }
 
+static_assert(sizeof(sg_wire_feature) == sizeof(WireRec) && offsetof(sg_wire_feature, desc) == offsetof(WireRec, desc) &&
+                  offsetof(sg_wire_feature, ori) == offsetof(WireRec, ori) &&
+                  offsetof(sg_wire_feature, val) == offsetof(WireRec, val) &&
+                  offsetof(sg_wire_feature, octave_scale) == offsetof(WireRec, oscale),
+              "the public wire record is the device's WireRec");
+
 static void expand_records(const WireRec *w, size_t n, sg_keypoint *out)
 {
     for (size_t i = 0; i < n; i++) {
@@ -1079,6 +1086,7 @@ int sg_extract_begin(sg_ctx *c, const uint8_t *px, int width, int height, int ch
     if (!c || !px || !n)
         return SG_E_INVALID;
     (void)hipSetDevice(c->prm.device);
+    c->pending_counts.clear();
     c->have_pending = false;
     if (width < 1 || height < 1 || channels < 3 || stride < (size_t)width * channels)
         return fail(c, SG_E_INVALID, "stride is smaller than a row of pixels");
@@ -1130,6 +1138,107 @@ int sg_extract_fetch(sg_ctx *c, sg_keypoint *out, size_t cap, size_t *n)
     pack_phase(c, c->d_out, nf, (unsigned int)nf, nullptr, 3, 1, 1);
     HIPCHK(c, hipGetLastError());
     return download_records(c, out, (const WireRec *)c->d_out, nf);
+}
+
+int sg_extract_batch_begin(sg_ctx *c, const uint8_t *const *imgs, int n_img, int width, int height, int channels,
+                           size_t stride, int pinned, uint32_t *counts)
+{
+    if (!c || !imgs || !counts || n_img < 1 || n_img > c->B)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    c->pending_counts.clear();
+    c->have_pending = false;
+    if (width < 1 || height < 1 || channels < 3 || stride < (size_t)width * channels)
+        return fail(c, SG_E_INVALID, "stride is smaller than a row of pixels");
+    for (int i = 0; i < n_img; i++)
+        if (!imgs[i])
+            return SG_E_INVALID;
+    const size_t img_bytes = stride * (size_t)height, nbytes = image_bytes(width, height, channels, stride);
+    int rc = ensure_in(c, img_bytes * n_img);
+    if (rc != SG_OK)
+        return rc;
+    const bool staged = !pinned && ensure_pinned_in(c, img_bytes * n_img) == SG_OK;
+    for (int i = 0; i < n_img; i++) {
+        const uint8_t *src = imgs[i];
+        if (staged) {
+            memcpy(c->h_in + img_bytes * i, imgs[i], nbytes);
+            src = c->h_in + img_bytes * i;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_in + img_bytes * i, src, nbytes, hipMemcpyHostToDevice, c->stream));
+    }
+    rc = run_pipeline(c, c->d_in, n_img, width, height, channels, stride, img_bytes);
+    if (rc != SG_OK)
+        return rc;
+    HIPCHK(c, hipMemcpyAsync(counts, c->d_counts + 2 * c->B, sizeof(uint32_t) * n_img, hipMemcpyDeviceToHost,
+                             c->stream));
+    rc = check_overflow(c); // synchronises
+    if (rc != SG_OK)
+        return rc;
+    c->pending_counts.assign(counts, counts + n_img);
+    return SG_OK;
+}
+
+int sg_extract_batch_fetch_wire(sg_ctx *c, sg_wire_feature *out, size_t cap_total)
+{
+    if (!c || (cap_total && !out))
+        return SG_E_INVALID;
+    if (c->pending_counts.empty())
+        return fail(c, SG_E_INVALID, "sg_extract_batch_fetch_wire without a successful sg_extract_batch_begin before it");
+    (void)hipSetDevice(c->prm.device);
+    const int n_img = (int)c->pending_counts.size();
+    size_t total = 0, widest = 0;
+    for (uint32_t v : c->pending_counts) {
+        total += v;
+        widest = std::max<size_t>(widest, v);
+    }
+    if (total > cap_total)
+        return fail(c, SG_E_CAPACITY, "output array too small");
+    if (total == 0)
+        return SG_OK;
+    // every image packs into a slot of `widest` records; the slots come down back to back
+    int rc = ensure_out(c, sizeof(WireRec) * widest * n_img);
+    if (rc != SG_OK)
+        return rc;
+    pack_phase(c, c->d_out, widest, (unsigned int)widest, nullptr, 3, 1, n_img);
+    HIPCHK(c, hipGetLastError());
+    size_t at = 0;
+    for (int i = 0; i < n_img; i++) {
+        const size_t cnt = c->pending_counts[i];
+        if (cnt)
+            HIPCHK(c, hipMemcpyAsync(out + at, (const WireRec *)c->d_out + widest * i, cnt * sizeof(WireRec),
+                                     hipMemcpyDeviceToHost, c->stream));
+        at += cnt;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return SG_OK;
+}
+
+void sg_expand_wire(const sg_wire_feature *in, size_t n, sg_keypoint *out)
+{
+    if (in && out)
+        expand_records(reinterpret_cast<const WireRec *>(in), n, out);
+}
+
+int sg_host_alloc(size_t bytes, void **ptr)
+{
+    if (!ptr || bytes == 0)
+        return SG_E_INVALID;
+    *ptr = nullptr;
+    if (hipHostMalloc(ptr, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *ptr = nullptr;
+        return SG_E_NOMEM;
+    }
+    return SG_OK;
+}
+
+int sg_host_free(void *ptr)
+{
+    if (ptr && hipHostFree(ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return SG_E_HIP;
+    }
+    return SG_OK;
 }
 
 int sg_extract(sg_ctx *c, const uint8_t *px, int width, int height, int channels, size_t stride, sg_keypoint *out,

@@ -137,3 +137,8 @@ const char *SiftLastError();     // text for it
 void SiftSetDevice(int device);  // HIP device used by later calls on this thread (default 0)
 void SiftSetVerbose(bool on);    // print the reference's progress lines (sift.cpp:1654-1706); default off
 void SiftReleaseContext();       // free this thread's GPU context
+// Sift()/Sift_nointerval() calls of all threads share one context per device that runs up to max_batch images per
+// batch (whatever is waiting when the context falls idle; nobody waits for a batch to fill).  0 or 1: every thread
+// drives a context of its own (the default; the environment variable SIFT_GPU_BATCH sets another default).  Call it
+// while no Sift() call is running: it frees the shared contexts.
+void SiftSetBatching(int max_batch);

@@ -4,10 +4,16 @@
 // reference's calling conventions (void returns, outputs appended, silent return on bad arguments).
 #include "sift_gpu.h"
 
+#include <atomic>
 #include <cmath>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <iostream>
+#include <map>
+#include <mutex>
 
 #include "siftgpu.h"
 
@@ -145,6 +151,358 @@ void octave_dims(int rows, int cols, int octaves, std::vector<int> &r, std::vect
     }
 }
 
+// ---- one context shared by the calling threads ---------------------------------------------------------------
+// With SiftSetBatching(n > 1) the Sift() calls of all threads on a device go through one context of n images per batch.
+// A call copies its image into a page-locked slot and queues a request; whichever caller finds the context idle
+// becomes the leader: it takes the queued requests of one image size (its own need not be among them), runs them as
+// one batch and hands every request its slice of the downloaded wire records; each caller then expands its own
+// slice into its own vector while the next leader already runs the next batch.  Nobody waits for a batch to fill:
+// a caller alone gets a batch of one, sixteen busy callers settle into batches of about eight.
+struct Request {
+    const uint8_t *px = nullptr; // page-locked, rows back to back
+    int w = 0, h = 0, ch = 0;
+    double sigma = 0;
+    int nointerval = 0;
+    bool want_counters = false;
+    // filled by the leader
+    bool done = false;
+    int rc = SG_OK;
+    std::string error;
+    const sg_wire_feature *wire = nullptr;
+    size_t n = 0;
+    int wire_buf = -1;
+    sg_counters counters = {};
+    int octaves = 0;
+};
+
+class Batcher {
+public:
+    Batcher(int device, int max_batch) : device_(device), B_(max_batch), slots_(2 * (size_t)max_batch) {}
+
+    // a page-locked buffer of at least `bytes` for one caller's image; waits while all are taken
+    int acquire_slot(size_t bytes, uint8_t **p)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        size_t i;
+        for (;;) {
+            for (i = 0; i < slots_.size() && slots_[i].used; i++) {
+            }
+            if (i < slots_.size())
+                break;
+            cv_.wait(lk);
+        }
+        slots_[i].used = true;
+        lk.unlock(); // the slot is this caller's alone from here
+        if (slots_[i].cap < bytes) {
+            if (slots_[i].p)
+                sg_host_free(slots_[i].p);
+            slots_[i].p = nullptr;
+            slots_[i].cap = 0;
+            void *q = nullptr;
+            if (sg_host_alloc(bytes + bytes / 8, &q) != SG_OK) {
+                release_slot((int)i);
+                return -1;
+            }
+            slots_[i].p = static_cast<uint8_t *>(q);
+            slots_[i].cap = bytes + bytes / 8;
+        }
+        *p = slots_[i].p;
+        return (int)i;
+    }
+
+    void release_slot(int i)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        slots_[(size_t)i].used = false;
+        cv_.notify_all();
+    }
+
+    void release_wire(int b)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (--wire_[b].users == 0)
+            cv_.notify_all();
+    }
+
+    // queues r and returns once it has been served
+    void run(Request &r)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        queue_.push_back(&r);
+        while (!r.done) {
+            if (busy_) {
+                cv_.wait(lk);
+                continue;
+            }
+            busy_ = true;
+            std::vector<Request *> batch;
+            const Request *head = queue_.front();
+            for (auto it = queue_.begin(); it != queue_.end() && (int)batch.size() < B_;) {
+                const Request *q = *it;
+                if (q->w == head->w && q->h == head->h && q->ch == head->ch && q->sigma == head->sigma &&
+                    q->nointerval == head->nointerval) {
+                    batch.push_back(*it);
+                    it = queue_.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+            lk.unlock();
+            const int wb = execute(batch);
+            lk.lock();
+            if (wb >= 0) {
+                int users = 0;
+                for (Request *q : batch)
+                    users += q->wire_buf == wb;
+                wire_[wb].users = users; // 0: free again at once
+            }
+            for (Request *q : batch)
+                q->done = true;
+            busy_ = false;
+            cv_.notify_all();
+        }
+    }
+
+    void destroy()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        if (ctx_)
+            sg_destroy(ctx_);
+        ctx_ = nullptr;
+        for (WireBuf &w : wire_) {
+            if (w.p)
+                sg_host_free(w.p);
+            w = WireBuf();
+        }
+        for (Slot &sl : slots_) {
+            if (sl.p)
+                sg_host_free(sl.p);
+            sl = Slot();
+        }
+    }
+
+private:
+    struct Slot {
+        uint8_t *p = nullptr;
+        size_t cap = 0;
+        bool used = false;
+    };
+    struct WireBuf {
+        sg_wire_feature *p = nullptr;
+        size_t cap = 0;
+        int users = 0; // callers still expanding out of it; -1: held by the leader
+    };
+
+    bool make_context(int w, int h, double sigma, int ni, size_t min_features)
+    {
+        const bool fits = ctx_ && w <= max_w_ && h <= max_h_ && sigma == sigma_ && ni == ni_ && min_features <= max_features_;
+        if (fits)
+            return true;
+        if (min_features > max_features_)
+            max_features_ = min_features;
+        if (ctx_)
+            sg_destroy(ctx_);
+        ctx_ = nullptr;
+        sg_params p;
+        sg_default_params(&p);
+        p.sigma = sigma;
+        p.nointerval = ni;
+        p.max_width = w > max_w_ ? w : max_w_;
+        p.max_height = h > max_h_ ? h : max_h_;
+        p.max_batch = B_;
+        p.device = device_;
+        p.max_features = max_features_ > 0x7fffffff ? 0x7fffffff : (int)max_features_;
+        if (sg_create(&p, &ctx_) != SG_OK) {
+            ctx_ = nullptr;
+            max_w_ = max_h_ = 0;
+            return false;
+        }
+        max_w_ = p.max_width;
+        max_h_ = p.max_height;
+        sigma_ = sigma;
+        ni_ = ni;
+        return true;
+    }
+
+    static void fail_all(const std::vector<Request *> &batch, int rc, const char *what)
+    {
+        for (Request *q : batch) {
+            q->rc = rc;
+            q->error = what && *what ? what : sg_strerror(rc);
+        }
+    }
+
+    // runs one batch; returns the wire buffer its results lie in (-1: none)
+    int execute(const std::vector<Request *> &batch)
+    {
+        const Request &h = *batch[0];
+        const int n = (int)batch.size();
+        if (!make_context(h.w < 2 ? 2 : h.w, h.h < 2 ? 2 : h.h, h.sigma, h.nointerval, 0)) {
+            fail_all(batch, SG_E_HIP, "sg_create failed (is a HIP device present? there is no CPU fallback)");
+            return -1;
+        }
+        std::vector<const uint8_t *> imgs(batch.size());
+        for (int i = 0; i < n; i++)
+            imgs[(size_t)i] = batch[(size_t)i]->px;
+        std::vector<uint32_t> counts(batch.size());
+        int rc = SG_OK;
+        for (int attempt = 0; attempt < 4; attempt++) {
+            rc = sg_extract_batch_begin(ctx_, imgs.data(), n, h.w, h.h, h.ch, (size_t)h.w * h.ch, 1, counts.data());
+            if (rc != SG_E_CAPACITY)
+                break;
+            size_t need = 0; // an image denser than the context was sized for: a larger context, and again
+            if (sg_required_features(ctx_, &need) != SG_OK || need <= max_features_ ||
+                !make_context(h.w, h.h, h.sigma, h.nointerval, need))
+                break;
+        }
+        if (rc != SG_OK) {
+            fail_all(batch, rc, ctx_ ? sg_last_error(ctx_) : "");
+            return -1;
+        }
+        size_t total = 0;
+        for (uint32_t v : counts)
+            total += v;
+        for (int i = 0; i < n; i++) {
+            Request *q = batch[(size_t)i];
+            q->octaves = sg_last_octaves(ctx_);
+            if (q->want_counters)
+                sg_read_counters(ctx_, i, &q->counters);
+        }
+        if (total == 0)
+            return -1; // rc OK, n 0 everywhere
+        int wb;
+        {
+            std::unique_lock<std::mutex> lk(m_);
+            for (;;) {
+                wb = wire_[0].users == 0 ? 0 : wire_[1].users == 0 ? 1 : -1;
+                if (wb >= 0)
+                    break;
+                cv_.wait(lk);
+            }
+            wire_[wb].users = -1;
+        }
+        WireBuf &w = wire_[wb];
+        if (w.cap < total) {
+            if (w.p)
+                sg_host_free(w.p);
+            w.p = nullptr;
+            w.cap = 0;
+            void *q = nullptr;
+            const size_t cap = total + total / 4;
+            if (sg_host_alloc(cap * sizeof(sg_wire_feature), &q) != SG_OK) {
+                fail_all(batch, SG_E_NOMEM, "no page-locked memory for the feature records");
+                return wb; // users counts to 0 in run(): free again
+            }
+            w.p = static_cast<sg_wire_feature *>(q);
+            w.cap = cap;
+        }
+        rc = sg_extract_batch_fetch_wire(ctx_, w.p, w.cap);
+        if (rc != SG_OK) {
+            fail_all(batch, rc, sg_last_error(ctx_));
+            return wb;
+        }
+        size_t at = 0;
+        for (int i = 0; i < n; i++) {
+            Request *q = batch[(size_t)i];
+            q->n = counts[(size_t)i];
+            if (q->n) {
+                q->wire = w.p + at;
+                q->wire_buf = wb;
+            }
+            at += q->n;
+        }
+        return wb;
+    }
+
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::deque<Request *> queue_;
+    bool busy_ = false;
+    const int device_, B_;
+    sg_ctx *ctx_ = nullptr;
+    int max_w_ = 0, max_h_ = 0, ni_ = -1;
+    double sigma_ = 0;
+    size_t max_features_ = 0;
+    WireBuf wire_[2];
+    std::vector<Slot> slots_;
+};
+
+std::atomic<int> g_batching(-1); // -1: not set yet (the environment decides on first use)
+std::mutex g_batchers_mutex;
+std::map<int, Batcher *> g_batchers; // per device; live until SiftSetBatching() drops them
+
+int batching()
+{
+    int b = g_batching.load();
+    if (b < 0) {
+        const char *e = std::getenv("SIFT_GPU_BATCH");
+        b = e ? std::atoi(e) : 0;
+        if (b < 0)
+            b = 0;
+        if (b > 64)
+            b = 64;
+        int expected = -1;
+        g_batching.compare_exchange_strong(expected, b);
+        b = g_batching.load();
+    }
+    return b;
+}
+
+Batcher *batcher_for(int device, int max_batch)
+{
+    std::lock_guard<std::mutex> lk(g_batchers_mutex);
+    Batcher *&b = g_batchers[device];
+    if (!b)
+        b = new Batcher(device, max_batch);
+    return b;
+}
+
+void print_counters(const Mat &src, const sg_counters &c, int octaves, size_t n)
+{ // the reference's progress lines (sift.cpp:984-986, 1654-1706)
+    std::cout << "rows = " << 2 * src.rows << "  cols = " << 2 * src.cols << "  octaves = " << octaves << std::endl;
+    std::cout << "cc00: " << c.cc00 << ", cc0: " << c.cc0 << ", cc1: " << c.cc1 << ", cc2: " << c.cc2
+              << ", cc3: " << c.cc3 << std::endl;
+    std::cout << "keypoints cout: " << c.cc3 << std::endl;
+    std::cout << "features count: " << n << std::endl;
+}
+
+void run_sift_shared(const Mat &src, std::vector<Keypoint> &features, double sigma, int nointerval, int max_batch)
+{
+    Batcher *b = batcher_for(tls.device, max_batch);
+    const size_t row = (size_t)src.cols * src.channels();
+    uint8_t *slot_mem = nullptr;
+    const int slot = b->acquire_slot(row * (size_t)src.rows, &slot_mem);
+    if (slot < 0) {
+        set_status(SG_E_NOMEM, "no page-locked memory for the input image");
+        return;
+    }
+    for (int y = 0; y < src.rows; y++)
+        std::memcpy(slot_mem + row * (size_t)y, src.data + src.step * (size_t)y, row);
+    Request r;
+    r.px = slot_mem;
+    r.w = src.cols;
+    r.h = src.rows;
+    r.ch = src.channels();
+    r.sigma = sigma;
+    r.nointerval = nointerval;
+    r.want_counters = tls.verbose;
+    b->run(r);
+    b->release_slot(slot);
+    if (r.rc != SG_OK) {
+        set_status(r.rc, r.error.c_str());
+        return;
+    }
+    if (r.n) {
+        const size_t old = features.size();
+        features.resize(old + r.n);
+        sg_expand_wire(r.wire, r.n, reinterpret_cast<sg_keypoint *>(features.data() + old));
+        b->release_wire(r.wire_buf);
+    }
+    set_status(SG_OK);
+    if (tls.verbose)
+        print_counters(src, r.counters, r.octaves, r.n);
+}
+
 void run_sift(const Mat &src, std::vector<Keypoint> &features, double sigma, int intervals, int nointerval)
 {
     if (src.empty() || src.depth() != CV_8U || src.channels() < 3) {
@@ -153,6 +511,11 @@ void run_sift(const Mat &src, std::vector<Keypoint> &features, double sigma, int
     }
     if (intervals != INTERVALS) {
         set_status(SG_E_UNSUPPORTED, "only intervals == 3 is supported (the reference hard-wires INTERVALS)");
+        return;
+    }
+    const int shared = batching();
+    if (shared > 1) {
+        run_sift_shared(src, features, sigma, nointerval, shared);
         return;
     }
     sg_ctx *ctx = context_for(src.cols, src.rows, sigma, nointerval);
@@ -179,15 +542,10 @@ void run_sift(const Mat &src, std::vector<Keypoint> &features, double sigma, int
         features.resize(old);
         return;
     }
-    if (tls.verbose) { // the reference's progress lines (sift.cpp:984-986, 1654-1706)
+    if (tls.verbose) {
         sg_counters c;
         sg_read_counters(ctx, 0, &c);
-        std::cout << "rows = " << 2 * src.rows << "  cols = " << 2 * src.cols << "  octaves = " << sg_last_octaves(ctx)
-                  << std::endl;
-        std::cout << "cc00: " << c.cc00 << ", cc0: " << c.cc0 << ", cc1: " << c.cc1 << ", cc2: " << c.cc2
-                  << ", cc3: " << c.cc3 << std::endl;
-        std::cout << "keypoints cout: " << c.cc3 << std::endl;
-        std::cout << "features count: " << n << std::endl;
+        print_counters(src, c, sg_last_octaves(ctx), n);
     }
 }
 
@@ -269,6 +627,20 @@ void SiftSetDevice(int device)
     tls.device = device;
 }
 void SiftSetVerbose(bool on) { tls.verbose = on; }
+void SiftSetBatching(int max_batch)
+{
+    if (max_batch < 0)
+        max_batch = 0;
+    if (max_batch > 64)
+        max_batch = 64;
+    std::lock_guard<std::mutex> lk(g_batchers_mutex);
+    for (auto &kv : g_batchers) {
+        kv.second->destroy();
+        delete kv.second;
+    }
+    g_batchers.clear();
+    g_batching.store(max_batch);
+}
 void SiftReleaseContext()
 {
     if (tls.ctx)

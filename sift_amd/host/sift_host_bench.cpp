@@ -1,8 +1,9 @@
 // sift_host_bench.cpp -- the reference's own entry point, Sift(const Mat &, vector<Keypoint> &) (sift/sift.h:139),
 // timed as a caller sees it: host image in, 1120-byte records appended to a host vector.
-//   sift_host_bench <width> <height> <threads> <calls per thread> [device]
+//   sift_host_bench <width> <height> <threads> <calls per thread> [device] [shared batch]
 // One thread alone gives the latency of a call; T threads, each with its own context (the layer keeps one per thread)
-// and its own frame, give the throughput one GPU delivers through this interface.  Prints one JSON object.
+// and its own frame, give the throughput one GPU delivers through this interface; with a shared batch > 1 the threads
+// share one context instead (SiftSetBatching).  Prints one JSON object.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -23,6 +24,7 @@ int main(int argc, char **argv)
     }
     const int w = std::atoi(argv[1]), h = std::atoi(argv[2]), T = std::atoi(argv[3]), N = std::atoi(argv[4]);
     const int device = argc > 5 ? std::atoi(argv[5]) : 0;
+    const int shared = argc > 6 ? std::atoi(argv[6]) : 0;
     std::vector<Mat> frames;
     for (int t = 0; t < (T > 0 ? T : 1); t++)
         frames.push_back(make_image(w, h, 1000 + (uint64_t)t));
@@ -55,6 +57,8 @@ int main(int argc, char **argv)
     }
 
     // ---- T threads ----
+    SiftReleaseContext();
+    SiftSetBatching(shared);
     std::vector<int> status(T > 0 ? T : 1, 0);
     std::vector<std::thread> th;
     std::vector<size_t> counts(T > 0 ? T : 1, 0);
@@ -90,7 +94,7 @@ int main(int argc, char **argv)
             return 1;
         }
     std::printf("{\"width\": %d, \"height\": %d, \"features\": %zu, \"sift_ms_single\": %.3f, \"sift_ms_single_best\": %.3f, "
-                "\"sift_ms_fresh_vector\": %.3f, \"threads\": %d, \"calls\": %d, \"images_per_s\": %.1f}\n",
-                w, h, n_feat, sum / reps, best, fresh, T, T * N, T > 0 ? 1e3 * T * N / wall : 0.0);
+                "\"sift_ms_fresh_vector\": %.3f, \"threads\": %d, \"shared_batch\": %d, \"calls\": %d, \"images_per_s\": %.1f}\n",
+                w, h, n_feat, sum / reps, best, fresh, T, shared, T * N, T > 0 ? 1e3 * T * N / wall : 0.0);
     return 0;
 }

@@ -4,10 +4,16 @@
 //   views <w> <h> <seed>             Sift() on a 4-channel frame and on a padded view (step > cols * channels, last
 //                                    row ending at the end of its buffer) equals Sift() on the packed 3-channel frame
 //   legacy                           the reference's off-path helpers (8-bit legacy blurs, dump names)
+//   shared <w> <h> <threads> <calls> <batch>
+//                                    threads calling Sift()/Sift_nointerval() through one shared context
+//                                    (SiftSetBatching) get the records a context of their own returns: frames of two
+//                                    sizes, both detectors and one frame denser than the default sizing in the mix
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 
 #include "sift_gpu.h"
 #include "synth_image.h"
@@ -95,6 +101,60 @@ int main(int argc, char **argv)
         std::printf("legacy ok\n");
         return 0;
     }
-    std::fprintf(stderr, "usage: %s dense w h cell out.txt | views w h seed | legacy\n", argv[0]);
+    if (mode == "shared" && argc == 7) {
+        const int w = std::atoi(argv[2]), h = std::atoi(argv[3]), T = std::atoi(argv[4]), N = std::atoi(argv[5]);
+        const int batch = std::atoi(argv[6]);
+        struct Job {
+            Mat img;
+            bool nointerval;
+            std::vector<Keypoint> want;
+        };
+        std::vector<Job> jobs((size_t)T);
+        for (int t = 0; t < T; t++) {
+            Job &j = jobs[(size_t)t];
+            if (t % 5 == 3)
+                j.img = make_image(w / 2 + 1, h / 2 - 1, 77 + (uint64_t)t); // a second, odd size
+            else if (t == 6)
+                j.img = make_checker_image(w, h, 3); // overflows the default sizing: the shared context must grow
+            else
+                j.img = make_image(w, h, 1000 + (uint64_t)t);
+            j.nointerval = t % 4 == 1;
+            if (j.nointerval)
+                Sift_nointerval(j.img, j.want, SIGMA);
+            else
+                Sift(j.img, j.want, SIGMA);
+            if (SiftLastStatus() != 0 || j.want.empty())
+                return fail("Sift with a context of the thread's own");
+        }
+        SiftReleaseContext();
+        SiftSetBatching(batch);
+        std::atomic<int> bad(0);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t] {
+                const Job &j = jobs[(size_t)t];
+                for (int i = 0; i < N; i++) {
+                    std::vector<Keypoint> got;
+                    if (j.nointerval)
+                        Sift_nointerval(j.img, got, SIGMA);
+                    else
+                        Sift(j.img, got, SIGMA);
+                    if (SiftLastStatus() != 0 || !same_features(j.want, got)) {
+                        std::fprintf(stderr, "thread %d call %d: status %d (%s), %zu features, %zu expected\n", t, i,
+                                     SiftLastStatus(), SiftLastError(), got.size(), j.want.size());
+                        bad++;
+                        return;
+                    }
+                }
+            });
+        for (std::thread &x : th)
+            x.join();
+        SiftSetBatching(0);
+        if (bad)
+            return fail("shared context");
+        std::printf("shared ok: %d threads x %d calls\n", T, N);
+        return 0;
+    }
+    std::fprintf(stderr, "usage: %s dense w h cell out.txt | views w h seed | legacy | shared w h threads calls batch\n", argv[0]);
     return 2;
 }

@@ -71,3 +71,13 @@ def test_four_channel_and_padded_views():
     out = subprocess.run([exe, "views", "200", "150", "31"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "views ok" in out.stdout
+
+
+def test_threads_sharing_one_context_get_their_own_records():
+    """SiftSetBatching: 12 threads call Sift()/Sift_nointerval() through one shared context, frames of two sizes and one
+    frame denser than the default sizing in the mix; every call returns, byte for byte, what a context of the thread's
+    own returned before."""
+    exe = _need("sift_host_check")
+    out = subprocess.run([exe, "shared", "320", "240", "12", "6", "8"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "shared ok: 12 threads x 6 calls" in out.stdout

@@ -211,6 +211,33 @@ def test_batch_device_matches_single(oracle, gpu64):
         assert out[i, : cnt[i]].tobytes() == packed[i].tobytes()
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_batch_wire_records_equal_single_image_records(oracle, pinned):
+    """sg_extract_batch_begin / sg_extract_batch_fetch_wire / sg_expand_wire: several host images in one batch come
+    back as the same 1120-byte records, byte for byte, that sg_extract returns for each alone (an image without
+    features in the middle of the batch included)."""
+    import sift_amd
+    w, h, n = 150, 113, 4
+    imgs = np.stack([oracle.vnoise5(w, h, 300 + i) for i in range(n)])
+    imgs[2] = 90  # flat: no features
+    with sift_amd.SiftGPU(max_width=w, max_height=h, max_batch=n) as g:
+        singles = [g.extract(imgs[i]) for i in range(n)]
+        got = g.extract_batch_wire(imgs, pinned=pinned)
+        assert [len(x) for x in got] == [len(x) for x in singles] and len(singles[2]) == 0 and len(singles[0]) > 50
+        def same(a, b):  # field by field: a copy of a numpy record array leaves the padding bytes undefined
+            return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+        for a, b in zip(got, singles):
+            assert same(a, b)
+        # fewer images than the context's batch, and a fetch into too small an array
+        got = g.extract_batch_wire(imgs[:2], pinned=pinned)
+        assert same(got[1], singles[1])
+        wire = np.zeros(4, dtype=sift_amd.WIRE_DTYPE)
+        assert g.lib.sg_extract_batch_fetch_wire(g.ctx, wire.ctypes.data, 4) == sift_amd.api.SG_E_CAPACITY
+        # a single-image call in between drops the pending batch
+        g.extract(imgs[0])
+        assert g.lib.sg_extract_batch_fetch_wire(g.ctx, wire.ctypes.data, 4) == sift_amd.api.SG_E_INVALID
+
+
 def test_batch_device_output_at_unaligned_address(oracle, gpu64):
     """Packed records are 4-byte aligned by type; an output buffer that does not start on a 16-byte boundary takes
     the packing kernel's other form and gives the same records."""

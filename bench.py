@@ -326,12 +326,42 @@ def main():
         g_outs = [torch.empty(cap_all * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         g_cnts = [torch.zeros(world * B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
         if world == 1 or dist.get_backend() == "nccl":
-            xctx = sift_amd.SiftGPU(max_width=64, max_height=64, max_batch=1, device=dev_index)
-            ids = [sift_amd.api.comm_unique_id() if rank == 0 else None]
-            if world > 1:
-                dist.broadcast_object_list(ids, src=0)
-            comm = xctx.comm_create(ids[0], rank, world)
-            exchange = "sg_allgather_features (RCCL all-gather-v)"
+            # Every rank first checks on its own that the library can bind RCCL, and the ranks agree on the outcome
+            # before any of them enters the collective set-up: a rank that cannot must not leave the others waiting.
+            why = ""
+
+            def all_ok(ok):
+                if world == 1:
+                    return ok
+                t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item())
+
+            try:
+                my_id = sift_amd.api.comm_unique_id()
+                ok = True
+            except Exception as e:
+                ok, why = False, repr(e)
+            if all_ok(ok):
+                try:
+                    xctx = sift_amd.SiftGPU(max_width=64, max_height=64, max_batch=1, device=dev_index)
+                    ids = [my_id if rank == 0 else None]
+                    if world > 1:
+                        dist.broadcast_object_list(ids, src=0)
+                    comm = xctx.comm_create(ids[0], rank, world)
+                except Exception as e:
+                    ok, why = False, repr(e)
+                ok = all_ok(ok)
+            if ok:
+                exchange = "sg_allgather_features (RCCL all-gather-v)"
+            else:
+                if xctx is not None:
+                    xctx.close()
+                xctx = comm = None
+                if world == 1:
+                    raise RuntimeError("the exchange step needs RCCL through the C ABI: " + why)
+                exchange = ("torch.distributed all-gather-v over %s (RCCL through the C ABI was not usable on every "
+                            "rank%s)" % (dist.get_backend(), ": " + why if why else ""))
         else:
             exchange = "torch.distributed all-gather-v (%s rehearsal)" % dist.get_backend()
     gathered_total = [0] * nbuf   # features in the gathered buffer b
@@ -359,7 +389,9 @@ def main():
                 gathered_total[b] = first[-1]
                 gather_busy[b] = True
             else:
-                gv, gc, first = sdist.allgather_features_v(outs[b].cpu(), cnts[b].cpu(), cap)
+                on_dev = dist.get_backend() == "nccl"
+                gv, gc, first = sdist.allgather_features_v(outs[b] if on_dev else outs[b].cpu(),
+                                                           cnts[b] if on_dev else cnts[b].cpu(), cap)
                 gathered_total[b] = first[-1]
 
     def submit(step):

@@ -30,6 +30,7 @@ def test_bench_small_workload():
     # the untimed extras: every frame of the last batch equals the frame run alone; Sift() through the host layer
     assert line["batch_check"]["ok"] is True and line["batch_check"]["frames"] == 4
     assert line["host_api"]["images_per_s"] > 0 and line["host_api"]["sift_ms_single"] > 0
+    assert line["host_api"]["images_per_s_shared_context"] > 0
     # the exchange step ran through the C ABI (a communicator of one rank) and gathered this rank's features unpadded
     assert "sg_allgather_features" in line["exchange"]
     assert line["features_gathered_last_step"] == line["features_last_step"] > 0

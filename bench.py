@@ -206,6 +206,29 @@ def host_api_throughput(W, H, dev_index, cpu_threads):
         return {"error": repr(e)}
 
 
+def two_batches_in_flight(args, B):
+    """The same workload with two contexts of half the batch each, so that the histogram kernels of one batch
+    (vector-ALU work) run beside the pyramid kernels of the other (memory work).  Kernel durations measured that way no
+    longer describe a kernel running alone, which is why `value` and `roofline` come from the one-context run; this
+    is a second, separate run of this script and is reported beside them."""
+    import subprocess
+    if B < 2:
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--contexts", "2", "--batch", str(B // 2),
+           "--steps", str(2 * args.steps), "--warmup", str(2 * args.warmup), "--width", str(args.width),
+           "--height", str(args.height), "--precision", args.precision, "--cap", str(args.cap),
+           "--no-extras", "--no-cpu-baseline", "--no-profile"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        if p.returncode != 0:
+            return {"error": p.stderr.strip()[-300:]}
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        return {"images_per_s": r["value"], "contexts": 2, "batch_per_context": r["config"]["batch"],
+                "ms_per_step": r["ms_per_step"], "steps": r["steps"]}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -472,6 +495,11 @@ def main():
         verify, latency = batch_check_and_latency(sift_amd, torch, dev, dev_index, prec, W, H, cap, frames, frame_bytes,
                                                   last_first, B, outs[last_buf[0]], feat_counts)
         host_api = host_api_throughput(W, H, dev_index, args.cpu_threads)
+    overlap = None
+    if not args.no_extras and world == 1 and nctx == 1:
+        del frames, outs, cnts
+        torch.cuda.empty_cache()
+        overlap = two_batches_in_flight(args, B)
 
     images = K * B * world
     value = images / elapsed
@@ -607,7 +635,8 @@ def main():
         "valu_roofline": [r for r in (
             valu_roofline("descr_k<double,false>", work[0], stage_ms.get("descr", 0.0) / K) if esize == 8 else None,
             valu_roofline("orient_k<double,false>", work[1], stage_ms.get("orient", 0.0) / K) if esize == 8 else None) if r],
-        "batch_check": verify, "latency_ms": latency, "host_api": host_api, "exchange": exchange,
+        "batch_check": verify, "latency_ms": latency, "host_api": host_api,
+        "two_batches_in_flight": overlap, "exchange": exchange,
         "features_last_step": int(feat_counts.astype(np.int64).sum()), "features_gathered_last_step": gathered_last,
         "stage_ms_per_step": {k: v / K for k, v in stage_ms.items() if v > 0},
         "blur_kernels": blur, "detect_kernel": detect,

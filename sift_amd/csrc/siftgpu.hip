@@ -1224,7 +1224,8 @@ int sg_host_alloc(size_t bytes, void **ptr)
     if (!ptr || bytes == 0)
         return SG_E_INVALID;
     *ptr = nullptr;
-    if (hipHostMalloc(ptr, bytes, hipHostMallocDefault) != hipSuccess) {
+    // portable: usable by the contexts of every device of the process, whichever device is current here
+    if (hipHostMalloc(ptr, bytes, hipHostMallocPortable) != hipSuccess) {
         (void)hipGetLastError();
         *ptr = nullptr;
         return SG_E_NOMEM;

@@ -248,7 +248,16 @@ public:
                 }
             }
             lk.unlock();
-            const int wb = execute(batch);
+            int wb = -1;
+            try {
+                wb = execute(batch);
+            } catch (...) { // out of host memory in the bookkeeping: the batch fails, the context stays usable
+                fail_all(batch, SG_E_NOMEM, "out of host memory");
+                for (Request *q : batch)
+                    q->wire_buf = -1;
+                wb = held_wire_;
+            }
+            held_wire_ = -1;
             lk.lock();
             if (wb >= 0) {
                 int users = 0;
@@ -380,6 +389,7 @@ private:
                 cv_.wait(lk);
             }
             wire_[wb].users = -1;
+            held_wire_ = wb;
         }
         WireBuf &w = wire_[wb];
         if (w.cap < total) {
@@ -424,6 +434,7 @@ private:
     double sigma_ = 0;
     size_t max_features_ = 0;
     WireBuf wire_[2];
+    int held_wire_ = -1; // wire buffer the running batch has taken (leader only)
     std::vector<Slot> slots_;
 };
 

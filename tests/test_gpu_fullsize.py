@@ -1,5 +1,7 @@
 """Full-size configurations: known answers recorded from the reference's pipeline on the same seeded inputs,
 the oracle beside the HIP path at 1080p, and size-independent properties where the oracle is too slow."""
+import os
+
 import numpy as np
 import pytest
 
@@ -96,6 +98,32 @@ def test_8k_image_known_counts():
         assert (np.diff(f["scale"]) >= 0).all()
         assert f["x"].min() >= 0 and f["x"].max() < 7680 and f["y"].min() >= 0 and f["y"].max() < 4320
         assert f["desc"].max() <= 255 and f["desc"].any(axis=1).all()
+
+
+def test_8k_image_equals_oracle_digest(oracle):
+    """The 8K configuration against the oracle's full output, through a digest committed under tests/golden/ (the
+    oracle takes minutes at this size; tests/golden/make_golden_8k.py wrote the digest): counters, the
+    integer fields, dx / dy bit for bit and all descriptor bins of all 360 706 features in final order by hash, every
+    8th orientation and scale by value."""
+    import hashlib
+    import sift_amd
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sift_7680x4320_s1234.npz"))
+    img = oracle.vnoise5(7680, 4320, 1234)
+    with sift_amd.SiftGPU(max_width=7680, max_height=4320) as ctx:
+        f = ctx.extract(img, cap=400000)
+        assert list(ctx.read_counters()) == [int(v) for v in g["counters"]]
+        assert len(ctx.read_keypoints()) == int(g["keypoints"])
+    assert len(f) == int(g["features"]) == KNOWN_8K_S1234[1]
+    ints = np.ascontiguousarray(np.stack([f[k] for k in ("x", "y", "octave", "interval")], axis=1).astype("<i4"))
+    f64 = np.ascontiguousarray(np.stack([f[k] for k in ("dx", "dy")], axis=1).astype("<f8"))
+    desc = np.ascontiguousarray(f["descriptor"]).astype(np.uint8)
+    assert hashlib.sha256(ints.tobytes()).hexdigest() == str(g["sha_ints"])
+    assert hashlib.sha256(f64.tobytes()).hexdigest() == str(g["sha_f64"])
+    assert hashlib.sha256(desc.tobytes()).hexdigest() == str(g["sha_desc"])
+    d = np.abs(f["ori"][::8] - g["ori_every_8th"])
+    d = np.minimum(d, 2 * np.pi - d)
+    assert d.max() < 1e-9
+    assert np.allclose(f["scale"][::8], g["scale_every_8th"], rtol=1e-14, atol=0)
 
 
 def test_1080p_batch256_equals_single(oracle):

@@ -476,6 +476,7 @@ def main():
     feat_counts = cnts[last_buf[0]].cpu().numpy()
     work = ctxs[(WU + K - 1) % nctx].read_work_counters(B)  # trips of the histogram loops in the last batch
     pair_mask = ctxs[0].last_pair_octaves()  # octaves whose levels 1 and 2 came from one launch
+    tail_first = ctxs[0].last_tail_octave()  # octaves from here on came from the one pyramid-tail launch
     gathered_last = gathered_total[last_buf[0]] if do_exchange else None
 
     last_first = ((WU + K - 1) * B) % pool  # first frame of the last step's batch
@@ -531,11 +532,12 @@ def main():
         for lvl in range(6):
             key = "blur_%s%d" % (kind, lvl)
             ms, ln = stage_ms.get(key, 0.0), stage_launches.get(key, 0)
-            octs = dims[:1] if lvl == 0 else dims
+            octs = dims[:1] if lvl == 0 else dims[:tail_first]  # the tail's octaves are counted under pyr_tail
             if fused:
                 octs = [d for d in octs if min(d) > radius_name[lvl]]
             if fused and lvl in (1, 2):  # octaves whose levels 1 and 2 one launch made are counted under blur_pair
-                octs = [d for o, d in enumerate(dims) if min(d) > radius_name[lvl] and not (pair_mask >> o) & 1]
+                octs = [d for o, d in enumerate(dims[:tail_first])
+                        if min(d) > radius_name[lvl] and not (pair_mask >> o) & 1]
             nbytes = 2.0 * esize * float(sum(r * c for r, c in octs)) * B * K
             ups = fused and lvl == 0 and blur_mode in ("", "win")
             if ups:  # the base blur reads the double gray plane at input resolution instead of an upsampled plane
@@ -557,6 +559,17 @@ def main():
                              "avg_us": 1e3 * ms / max(ln, 1), "GBps": nbytes / (ms * 1e-3) / 1e9,
                              "bytes_per_launch_avg": nbytes / max(ln, 1),
                              "GBps_as_two_launches": nbytes * (4.0 / 3.0) / (ms * 1e-3) / 1e9}
+        tot_bytes += nbytes
+        tot_ms += ms
+    # The smallest octaves from one launch (pyr_tail_k: one workgroup per frame, planes in LDS): level 0 of its first
+    # octave read once, five levels of every octave and level 0 of the later ones written once.
+    ms, ln = stage_ms.get("pyr_tail", 0.0), stage_launches.get("pyr_tail", 0)
+    if ms > 0:
+        tail_px = [r * c for r, c in dims[tail_first:]]
+        nbytes = esize * float(tail_px[0] + 5 * sum(tail_px) + sum(tail_px[1:])) * B * K
+        blur["pyr_tail"] = {"kernel": "pyr_tail_k<%s> (octaves %d..%d)" % (tname, tail_first, len(dims) - 1), "taps": 27,
+                            "launches": int(ln), "avg_us": 1e3 * ms / max(ln, 1), "GBps": nbytes / (ms * 1e-3) / 1e9,
+                            "bytes_per_launch_avg": nbytes / max(ln, 1)}
         tot_bytes += nbytes
         tot_ms += ms
     # the kernel name the profiler reports merges stage slots that share a template instantiation (R=5: slots 0, 1)

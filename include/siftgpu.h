@@ -204,6 +204,9 @@ int sg_last_octaves(const sg_ctx *ctx);
 int sg_level_dims(const sg_ctx *ctx, int octave, int *rows, int *cols);
 /* bit o set: levels 1 and 2 of octave o of the last call were produced by one launch (timed under SG_ST_BLUR_PAIR) */
 unsigned int sg_last_pair_octaves(const sg_ctx *ctx);
+/* first octave of the last call whose levels all came from the one launch timed under SG_ST_PYR_TAIL (octaves small
+ * enough for a workgroup's LDS); the octave count when there was no such launch */
+int sg_last_tail_octave(const sg_ctx *ctx);
 /* Gaussian level (octave, level 0..5) of image `image` of the last call, converted to double */
 int sg_read_level(sg_ctx *ctx, int image, int octave, int level, double *dst);
 int sg_read_counters(sg_ctx *ctx, int image, sg_counters *out);
@@ -231,6 +234,7 @@ typedef enum sg_stage {
     SG_ST_DESCR,
     SG_ST_SORT,           /* rank + output packing */
     SG_ST_BLUR_PAIR,      /* pyramid levels 1 and 2 of an octave in one launch (not counted under the level slots) */
+    SG_ST_PYR_TAIL,       /* every level of the smallest octaves in one launch (not counted under the level slots) */
     SG_ST_COUNT
 } sg_stage;
 

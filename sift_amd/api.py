@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SIFTGPU_LIB") or os.path.join(_HERE, "libsiftgpu.so")
 SG_OK, SG_E_INVALID, SG_E_HIP, SG_E_CAPACITY, SG_E_UNSUPPORTED, SG_E_NOMEM = 0, -1, -2, -3, -4, -5
 SG_F64, SG_F32 = 0, 1
 STAGES = (("prep",) + tuple("blur_row%d" % i for i in range(6)) + tuple("blur_col%d" % i for i in range(6)) +
-          ("downsample", "detect", "compact", "refine", "orient", "descr", "sort", "blur_pair"))
+          ("downsample", "detect", "compact", "refine", "orient", "descr", "sort", "blur_pair", "pyr_tail"))
 
 # Mirror of the reference's struct Keypoint (sift/sift.h:75-102), 1120 bytes.
 KEYPOINT_DTYPE = np.dtype({
@@ -44,7 +44,7 @@ EXPORTS = (
     "sg_downsample", "sg_gaussian_smooth", "sg_create_init_smooth_gray", "sg_gaussian_pyramid", "sg_sub",
     "sg_dog_pyramid", "sg_detect_local_extrema", "sg_calculate_scale", "sg_half_features",
     "sg_orientation_assignment", "sg_descriptor_representation", "sg_sort_features", "sg_last_octaves",
-    "sg_level_dims", "sg_last_pair_octaves", "sg_read_level", "sg_read_counters", "sg_read_work_counters", "sg_read_keypoints", "sg_read_features_unsorted",
+    "sg_level_dims", "sg_last_pair_octaves", "sg_last_tail_octave", "sg_read_level", "sg_read_counters", "sg_read_work_counters", "sg_read_keypoints", "sg_read_features_unsorted",
     "sg_set_profiling", "sg_get_stage_times", "sg_reset_stage_times", "sg_malloc", "sg_free", "sg_memcpy_h2d",
     "sg_memcpy_d2h", "sg_synth_vnoise5", "sg_match", "sg_match_packed_device",
     "sg_match_packed_device_noalloc", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy",
@@ -137,6 +137,7 @@ def load_library():
     L.sg_last_octaves.argtypes = [vp]
     L.sg_last_pair_octaves.argtypes = [vp]
     L.sg_last_pair_octaves.restype = C.c_uint
+    L.sg_last_tail_octave.argtypes = [vp]
     L.sg_level_dims.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.sg_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]
     L.sg_read_counters.argtypes = [vp, C.c_int, C.POINTER(Counters)]
@@ -471,6 +472,10 @@ class SiftGPU:
     def last_pair_octaves(self):
         """Bit mask of the octaves whose levels 1 and 2 came from one launch in the last call."""
         return int(self.lib.sg_last_pair_octaves(self.ctx))
+
+    def last_tail_octave(self):
+        """First octave of the last call that came from the pyramid-tail launch (the octave count: none did)."""
+        return int(self.lib.sg_last_tail_octave(self.ctx))
 
     def read_level(self, octave, level, image=0):
         r, c = C.c_int(0), C.c_int(0)

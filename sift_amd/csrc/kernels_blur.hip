@@ -1266,6 +1266,229 @@ __global__ __launch_bounds__(256) void copy_plane_k(const T *src, T *dst, int ro
     dst[blockIdx.z * dimg + (size_t)y * dpitch + x] = src[blockIdx.z * simg + (size_t)y * spitch + x];
 }
 
+// ---- pyramid tail: the smallest octaves in one launch ---------------------------------------------------------
+// Below a few thousand pixels a blur launch is all latency: five dependent launches per octave, and a frame alone
+// spends more time in the last four octaves' launches than in the first octave's arithmetic.  Here one workgroup per
+// image keeps the current level in LDS (A), filters rows into a second plane (Bp) and columns back into A, writing
+// every level to its place in the pyramid on the way; the 2:1 decimation of level 3 goes out as the next octave's
+// level 0 and is read back when that octave starts.  The arithmetic and its order are those of the row and column
+// kernels above (borders by repeated reflection, as planes may be narrower than the kernel), so levels are
+// bit-identical to theirs.
+constexpr int kTailThreads = 1024;
+constexpr size_t kTailLdsBytes = 150u << 10; // of the 160 KB a workgroup may take
+
+template <typename T>
+struct TailTaps {
+    T k[kLevels - 1][kMaxTaps]; // level l: 2 * R[l-1] + 1 taps, the kernel centred and zero-padded to that width
+    int R[kLevels - 1];         // 5, 6, 8, 10 or 13
+};
+
+constexpr int kTailHalo = 14; // columns of reflected border kept on either side of a row of A (R <= 13, pairs: +1)
+
+// Reflected border columns of A (rows x cols pixels at pitch cols + 2 * kTailHalo, first pixel of a row at +kTailHalo)
+template <typename T>
+__device__ __forceinline__ void tail_fill_halo(T *A, int rows, int cols, int tid)
+{
+    const int pa = cols + 2 * kTailHalo;
+    for (int idx = tid; idx < rows * 2 * kTailHalo; idx += kTailThreads) {
+        const int y = idx / (2 * kTailHalo), j = idx - y * (2 * kTailHalo);
+        const int c = j < kTailHalo ? j - kTailHalo : cols + (j - kTailHalo);
+        A[y * pa + kTailHalo + c] = A[y * pa + kTailHalo + reflect101(c, cols)];
+    }
+}
+
+// One level: rows of A (with its reflected border columns) filtered into Bp, columns of Bp filtered back into A and
+// out to the pyramid.  A thread takes two horizontally adjacent pixels in the row pass and two vertically adjacent
+// ones in the column pass: the pair shares all but one of its window's LDS reads, and LDS bandwidth is what bounds a
+// workgroup that filters out of LDS.  Taps live in scalar registers.  Column windows that cross the top or bottom
+// take reflected row indices (one reflection suffices while rows > R + 1, the general loop otherwise).
+template <typename T, int R>
+__device__ __forceinline__ void tail_level(T *A, T *Bp, T *out, int rows, int cols, int pitch, const T *kp, int tid)
+{
+    T k[2 * R + 1];
+#pragma unroll
+    for (int t = 0; t <= 2 * R; t++)
+        k[t] = kp[t];
+    const int pa = cols + 2 * kTailHalo;
+    const int xpairs = (cols + 1) >> 1, ypairs = (rows + 1) >> 1;
+    for (int idx = tid; idx < rows * xpairs; idx += kTailThreads) { // generic row filter, left to right
+        const int y = idx / xpairs, x = 2 * (idx - y * xpairs);
+        const T *p = A + y * pa + kTailHalo + (x - R);
+        T w[2 * R + 2];
+#pragma unroll
+        for (int q = 0; q < 2 * R + 2; q++)
+            w[q] = p[q];
+        T acc0 = k[0] * w[0], acc1 = k[0] * w[1];
+#pragma unroll
+        for (int t = 1; t <= 2 * R; t++) {
+            acc0 = blur_madd(acc0, k[t], w[t]);
+            acc1 = blur_madd(acc1, k[t], w[t + 1]);
+        }
+        Bp[y * cols + x] = acc0;
+        if (x + 1 < cols)
+            Bp[y * cols + x + 1] = acc1;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < ypairs * cols; idx += kTailThreads) { // symmetric column filter, centre outwards
+        const int yp = idx / cols, x = idx - yp * cols, y = 2 * yp;
+        const bool two = y + 1 < rows;
+        T acc0, acc1 = (T)0;
+        if (rows > R + 1) {
+            T w[2 * R + 2];
+            if (y >= R && y + 1 + R < rows) {
+#pragma unroll
+                for (int q = 0; q < 2 * R + 2; q++)
+                    w[q] = Bp[(y - R + q) * cols + x];
+            } else {
+#pragma unroll
+                for (int q = 0; q < 2 * R + 2; q++)
+                    w[q] = Bp[reflect101_once(y - R + q, rows) * cols + x];
+            }
+            acc0 = k[R] * w[R];
+            acc1 = k[R] * w[R + 1];
+#pragma unroll
+            for (int t = 1; t <= R; t++) {
+                acc0 = blur_madd(acc0, k[R + t], w[R + t] + w[R - t]);
+                acc1 = blur_madd(acc1, k[R + t], w[R + 1 + t] + w[R + 1 - t]);
+            }
+        } else {
+            acc0 = kp[R] * Bp[y * cols + x];
+            for (int t = 1; t <= R; t++)
+                acc0 = blur_madd(acc0, kp[R + t],
+                                 Bp[reflect101(y + t, rows) * cols + x] + Bp[reflect101(y - t, rows) * cols + x]);
+            if (two) {
+                acc1 = kp[R] * Bp[(y + 1) * cols + x];
+                for (int t = 1; t <= R; t++)
+                    acc1 = blur_madd(acc1, kp[R + t], Bp[reflect101(y + 1 + t, rows) * cols + x] +
+                                                          Bp[reflect101(y + 1 - t, rows) * cols + x]);
+            }
+        }
+        A[y * pa + kTailHalo + x] = acc0;
+        out[(size_t)y * pitch + x] = acc0;
+        if (two) {
+            A[(y + 1) * pa + kTailHalo + x] = acc1;
+            out[(size_t)(y + 1) * pitch + x] = acc1;
+        }
+    }
+    __syncthreads();
+    tail_fill_halo(A, rows, cols, tid);
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(kTailThreads) void pyr_tail_k(OctaveTab tab, int first, TailTaps<T> taps,
+                                                           unsigned int a_elems)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    T *A = reinterpret_cast<T *>(smem_raw), *Bp = A + a_elems;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    for (int o = first; o < tab.octaves; o++) {
+        const int rows = tab.rows[o], cols = tab.cols[o], pitch = tab.pitch[o], npx = rows * cols;
+        const int pa = cols + 2 * kTailHalo;
+        // level 0: in place for the first octave, written by this workgroup (below) for the later ones
+        const T *lvl0 = (const T *)tab.lv[o][0] + (size_t)b * tab.img_stride[o];
+        for (int idx = tid; idx < npx; idx += kTailThreads) {
+            const int y = idx / cols, x = idx - y * cols;
+            A[y * pa + kTailHalo + x] = lvl0[(size_t)y * pitch + x];
+        }
+        __syncthreads();
+        tail_fill_halo(A, rows, cols, tid);
+        __syncthreads();
+        for (int l = 1; l < kLevels; l++) {
+            T *out = (T *)tab.lv[o][l] + (size_t)b * tab.img_stride[o];
+            const T *kp = taps.k[l - 1];
+            switch (taps.R[l - 1]) {
+            case 5: tail_level<T, 5>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            case 6: tail_level<T, 6>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            case 8: tail_level<T, 8>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            case 10: tail_level<T, 10>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            default: tail_level<T, 13>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            }
+            if (l == 3 && o + 1 < tab.octaves) { // DownSample: every second pixel of every second row
+                const int r2 = tab.rows[o + 1], c2 = tab.cols[o + 1], p2 = tab.pitch[o + 1];
+                T *next0 = (T *)tab.lv[o + 1][0] + (size_t)b * tab.img_stride[o + 1];
+                for (int idx = tid; idx < r2 * c2; idx += kTailThreads) {
+                    const int y = idx / c2, x = idx - y * c2;
+                    next0[(size_t)y * p2 + x] = A[(2 * y) * pa + kTailHalo + 2 * x];
+                }
+                // read back at the top of the next octave, after the barriers of levels 4 and 5
+            }
+        }
+    }
+}
+
+static int bucket_radius(int h);
+template <typename T>
+static Taps<T> padded_taps(const double *taps, int n, int R);
+
+template <typename T>
+static size_t tail_a_elems(const OctaveTab &tab, int first)
+{
+    return ((size_t)tab.rows[first] * (tab.cols[first] + 2 * kTailHalo) + 3) & ~(size_t)3;
+}
+
+template <typename T>
+static size_t tail_lds_bytes(const OctaveTab &tab, int first)
+{
+    return (tail_a_elems<T>(tab, first) + (size_t)tab.rows[first] * tab.cols[first]) * sizeof(T);
+}
+
+int pyr_tail_first(const OctaveTab &tab, const int *ntaps, int prec)
+{
+    if (!env().pyr_tail || tab.from_dog)
+        return tab.octaves;
+    for (int l = 0; l < kLevels - 1; l++)
+        if (ntaps[l] < 3 || ntaps[l] > kMaxTaps || ntaps[l] % 2 == 0)
+            return tab.octaves;
+    int first = tab.octaves;
+    for (int o = tab.octaves - 1; o >= 1; o--) {
+        // every octave of the tail halves the one before it (no dimension of 1, where DownSample copies and the
+        // kernel of a blur shrinks to one tap) and fits the workgroup's LDS
+        const bool halves = tab.rows[o] == tab.rows[o - 1] / 2 && tab.cols[o] == tab.cols[o - 1] / 2;
+        if (tab.rows[o] < 2 || tab.cols[o] < 2 || !halves)
+            break;
+        const size_t bytes = prec == SG_F64 ? tail_lds_bytes<double>(tab, o) : tail_lds_bytes<float>(tab, o);
+        if (bytes > kTailLdsBytes)
+            break;
+        first = o;
+    }
+    return first;
+}
+
+template <typename T>
+static bool tail_dispatch(const OctaveTab &tab, int first, int B, const double *const *taps, const int *ntaps,
+                          hipStream_t s)
+{
+    static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&pyr_tail_k<T>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTailLdsBytes) == hipSuccess;
+    if (!attr_ok) {
+        (void)hipGetLastError();
+        return false;
+    }
+    TailTaps<T> tt;
+    for (int l = 0; l < kLevels - 1; l++) {
+        const int R = bucket_radius(ntaps[l] / 2);
+        if (R < 0)
+            return false;
+        tt.R[l] = R;
+        const Taps<T> padded = padded_taps<T>(taps[l], ntaps[l], R);
+        for (int i = 0; i < kMaxTaps; i++)
+            tt.k[l][i] = padded.k[i];
+    }
+    pyr_tail_k<T><<<dim3(B), kTailThreads, tail_lds_bytes<T>(tab, first), s>>>(tab, first, tt,
+                                                                              (unsigned int)tail_a_elems<T>(tab, first));
+    return true;
+}
+
+bool launch_pyr_tail(const OctaveTab &tab, int first, int B, const double *const *taps, const int *ntaps, int prec,
+                     hipStream_t s)
+{
+    if (first < 1 || first >= tab.octaves || B < 1)
+        return false;
+    return prec == SG_F64 ? tail_dispatch<double>(tab, first, B, taps, ntaps, s)
+                          : tail_dispatch<float>(tab, first, B, taps, ntaps, s);
+}
+
 // ---- dispatch ---------------------------------------------------------------------------------------
 
 static int bucket_radius(int h)

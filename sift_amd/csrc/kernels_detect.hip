@@ -466,18 +466,19 @@ static void launch_detect_direct(const OctaveTab &tab, int o, int B, unsigned lo
 #undef SG_DET
 }
 
-// Scans every octave of the table that has pixels inside the border.  Consecutive octaves the staged kernel can take
+// Scans the octaves [o_from, o_to) of the table (all of them by default) that have pixels inside the border.  Consecutive octaves the staged kernel can take
 // share one launch; an octave it cannot take (rows not 16-byte aligned, planes of 2 GB and more) gets the direct kernel.
 // Returns the number of launches.
 int launch_detect(const OctaveTab &tab, int B, unsigned long long *words, size_t words_img_stride,
                   unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
-                  double thresh, int nointerval, int prec, hipStream_t s)
+                  double thresh, int nointerval, int prec, hipStream_t s, int o_from, int o_to)
 {
     const bool fd = tab.from_dog != 0, ni = nointerval != 0;
     constexpr int RS = SG_DET_RS, D = SG_DET_D;
     int launches = 0;
-    int o = 0;
-    while (o < tab.octaves) {
+    int o = o_from < 0 ? 0 : o_from;
+    const int o_stop = o_to < 0 || o_to > tab.octaves ? tab.octaves : o_to;
+    while (o < o_stop) {
         if (tab.nrows[o] <= 0 || tab.wpr[o] <= 0) {
             o++;
             continue;
@@ -494,7 +495,7 @@ int launch_detect(const OctaveTab &tab, int B, unsigned long long *words, size_t
             f = 0;
         dt.o_begin = o;
         unsigned long long tiles = 0;
-        while (o < tab.octaves && tab.nrows[o] > 0 && tab.wpr[o] > 0 && detect_staged_ok(tab, o, prec)) {
+        while (o < o_stop && tab.nrows[o] > 0 && tab.wpr[o] > 0 && detect_staged_ok(tab, o, prec)) {
             const unsigned long long t = (unsigned long long)((tab.wpr[o] + 3) / 4) * ((tab.nrows[o] + RS - 1) / RS) * B;
             if (tiles + t > 0xfffffff0ull)
                 break; // (never with this library's own allocations) the next launch takes it

@@ -32,6 +32,7 @@ struct Env {
     bool blur_direct = false, detect_direct = false;
     int blur_pair = 1; // SIFTGPU_BLUR_PAIR: 0 levels 1 and 2 always as two launches, 1 one launch where segments are
                        // long (default), 2 one launch wherever the plane is large enough (tests)
+    bool pyr_tail = true;               // SIFTGPU_PYR_TAIL=0: the smallest octaves level by level, like the large ones
     int ori_waves = 0, descr_waves = 0; // 0 = library default
     int n_cu = 256;                     // compute units of the current device at first use
 };
@@ -120,6 +121,13 @@ bool launch_blur_fused_upsampled(const Plane &gray, const Plane &dst, int B, con
 // does not apply (the caller then runs the two blurs one after the other)
 bool launch_blur_pair(const Plane &src, const Plane &dst_a, const Plane &dst_b, int B, const double *taps_a, int n_a,
                       const double *taps_b, int n_b, int prec, hipStream_t s);
+// The smallest octaves of a pyramid in one launch: one workgroup per image holds an octave's plane in LDS and produces
+// levels 1..5 of octaves first..tab.octaves-1 (and level 0 of every octave after `first`, by 2:1 decimation of level 3)
+// from level 0 of octave `first`, which must be in place.  taps[l-1], ntaps[l-1]: kernel of level l.
+// pyr_tail_first: the first octave (>= 1) from which that form applies, tab.octaves when none does.
+int pyr_tail_first(const OctaveTab &tab, const int *ntaps, int prec);
+bool launch_pyr_tail(const OctaveTab &tab, int first, int B, const double *const *taps, const int *ntaps, int prec,
+                     hipStream_t s);
 // true when launch_blur_fused can also write the 2:1 decimated copy of its output (DownSample) into `dec`
 bool blur_fused_decimates(const Plane &src, int n, int prec);
 
@@ -127,7 +135,7 @@ bool blur_fused_decimates(const Plane &src, int n, int prec);
 // all octaves of the table; returns the number of launches
 int launch_detect(const OctaveTab &tab, int B, unsigned long long *words, size_t words_img_stride,
                   unsigned int *chunk_sums, size_t chunks_img_stride, unsigned long long *counters,
-                  double thresh, int nointerval, int prec, hipStream_t s);
+                  double thresh, int nointerval, int prec, hipStream_t s, int o_from = 0, int o_to = -1);
 // exclusive scan of chunk_sums (n_chunks per image) in place; totals[b] = sum (clamped report of overflow)
 void launch_scan(unsigned int *chunk_sums, size_t chunks_img_stride, int n_chunks, unsigned int *totals,
                  unsigned int cap, unsigned int *overflow, int B, hipStream_t s);

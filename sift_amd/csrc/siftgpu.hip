@@ -32,6 +32,8 @@ const Env &env()
         v.detect_direct = getenv("SIFTGPU_DETECT_DIRECT") != nullptr;
         if (const char *pr = getenv("SIFTGPU_BLUR_PAIR"))
             v.blur_pair = strcmp(pr, "0") == 0 ? 0 : (strcmp(pr, "2") == 0 ? 2 : 1);
+        if (const char *t = getenv("SIFTGPU_PYR_TAIL"))
+            v.pyr_tail = strcmp(t, "0") != 0;
         if (const char *w = getenv("SIFTGPU_ORI_WAVES"))
             v.ori_waves = atoi(w);
         if (const char *w = getenv("SIFTGPU_DESCR_WAVES"))
@@ -170,6 +172,7 @@ struct sg_ctx {
 
     bool prof = false;
     unsigned int pair_octaves = 0; // octaves of the last call whose levels 1 and 2 came from one launch
+    int tail_octave = 0;           // first octave of the last call produced by the pyramid-tail launch (octaves: none)
     bool launch_failed = false; // a blur could not be launched (its taps found no device memory)
     bool fused_blur = true; // one-launch blur; SIFTGPU_BLUR=2pass selects the separate row/column kernels
     StageEvents ev;
@@ -387,18 +390,26 @@ static int set_geometry(sg_ctx *c, int w, int h, int B)
 
 // ---- keypoint stages (shared by the whole path and the stage entry points) ------------------------------
 
-static void detect_phase(sg_ctx *c, const OctaveTab &tab, unsigned int n_words, int B, int nointerval)
+constexpr double kDetectThreshold = 0.5 * 0.03 / 3; // 0.5 * DXTHRESHOLD / intervals (sift.cpp:924)
+
+// What a call starts from zero: chunk sums, counters and counts are one region, one fill.
+static void zero_work_area(sg_ctx *c) { (void)hipMemsetAsync(c->d_zero, 0, c->zero_bytes, c->stream); }
+
+// scanned_before: octaves below it have been scanned already (and the work area zeroed before that), see run_pipeline
+static void detect_phase(sg_ctx *c, const OctaveTab &tab, unsigned int n_words, int B, int nointerval,
+                         int scanned_before = 0)
 {
     hipStream_t s = c->stream;
     const int prec = c->prm.precision;
-    (void)hipMemsetAsync(c->d_zero, 0, c->zero_bytes, s); // chunk sums, counters and counts: one region, one fill
+    if (scanned_before == 0)
+        zero_work_area(c);
     unsigned int *ch1 = c->d_chunks, *ch2 = c->d_chunks + c->chunks1, *ch3 = ch2 + c->chunks2;
     (void)ch3;
-    const double thresh = 0.5 * 0.03 / 3; // 0.5 * DXTHRESHOLD / intervals (sift.cpp:924)
+    const double thresh = kDetectThreshold;
     {
         StageScope sc(c, SG_ST_DETECT, 0);
         const int launches = launch_detect(tab, B, c->d_words, c->words_img, ch1, c->chunks_total, c->d_ctr, thresh,
-                                           nointerval, prec, s);
+                                           nointerval, prec, s, scanned_before);
         if (c->prof)
             c->stage_launches[SG_ST_DETECT] += launches;
     }
@@ -581,7 +592,25 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
     }
     bool have_base = true; // level 0 of the octave is in place
     bool forked = false;
+    int side_octaves = 0; // octaves 0..side_octaves-1 have their levels 4 and 5 on the side stream
     c->pair_octaves = 0;
+    // The smallest octaves (planes that fit a workgroup's LDS) come from one launch after the loop.
+    const double *tail_taps[kLevels - 1];
+    int tail_ntaps[kLevels - 1];
+    for (int l = 1; l < kLevels; l++) {
+        tail_taps[l - 1] = c->taps[l];
+        tail_ntaps[l - 1] = c->ntaps[l];
+    }
+    const int tail = c->fused_blur ? pyr_tail_first(c->tab, tail_ntaps, prec) : c->octaves;
+    c->tail_octave = c->octaves;
+    // A frame alone: the tail launch keeps one compute unit busy for about as long as the scan of the octaves before
+    // it takes on the rest of the chip, so that scan runs beside it, on the side stream behind those octaves' levels 4
+    // and 5.  The work area it adds to is then zeroed here, ahead of everything.
+    const bool scan_beside_tail = tail >= 1 && tail < c->octaves && c->side && !c->prof &&
+                                  (size_t)B * c->rows[0] * c->cols[0] <= kSideStreamPixels;
+    int scanned_before = 0;
+    if (scan_beside_tail)
+        zero_work_area(c);
     for (int o = 0; o < c->octaves; o++) {
         if (!have_base) {
             StageScope sc(c, SG_ST_DOWNSAMPLE);
@@ -590,6 +619,19 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
                                      c->esize * c->level[o][0].img_stride * B, hipMemcpyDeviceToDevice, s);
             else
                 launch_downsample(c->level[o - 1][3], c->level[o][0], B, prec, s);
+        }
+        if (o == tail) { // level 0 of the first tail octave is in place: one launch takes the pyramid from here
+            StageScope sc(c, SG_ST_PYR_TAIL);
+            if (launch_pyr_tail(c->tab, tail, B, tail_taps, tail_ntaps, prec, s)) {
+                c->tail_octave = tail;
+                if (scan_beside_tail && side_octaves == tail) { // every octave before the tail has its levels 4, 5 there
+                    launch_detect(c->tab, B, c->d_words, c->words_img, c->d_chunks, c->chunks_total, c->d_ctr,
+                                  kDetectThreshold, c->prm.nointerval, prec, c->side, 0, tail);
+                    scanned_before = tail;
+                }
+                break;
+            }
+            sc.cancel();
         }
         have_base = false;
         // Levels 4 and 5 feed nothing but the extrema scan, while the next octave starts from level 3.  Where a launch
@@ -617,6 +659,8 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
                 (void)hipEventRecord(c->side_ev[0], s);
                 (void)hipStreamWaitEvent(c->side, c->side_ev[0], 0);
                 forked = true;
+                if (side_octaves == o)
+                    side_octaves = o + 1;
             }
             const bool wrote = blur_planes(c, c->level[o][l - 1], c->level[o][l], B, c->taps[l], c->ntaps[l], l,
                                            want_dec ? &c->level[o + 1][0] : nullptr, l >= 4 && side_ok ? c->side : nullptr);
@@ -630,7 +674,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
     }
     if (c->launch_failed)
         return fail(c, SG_E_NOMEM, "out of device memory (blur taps)");
-    detect_phase(c, c->tab, c->n_words, B, c->prm.nointerval);
+    detect_phase(c, c->tab, c->n_words, B, c->prm.nointerval, scanned_before);
     orient_phase(c, c->tab, B, ori_max_radius(c->prm));
     descr_phase(c, c->tab, B, descr_max_radius(c->prm));
     rank_phase(c, B);
@@ -1258,6 +1302,7 @@ int sg_extract(sg_ctx *c, const uint8_t *px, int width, int height, int channels
 int sg_last_octaves(const sg_ctx *c) { return c ? c->octaves : 0; }
 
 unsigned int sg_last_pair_octaves(const sg_ctx *c) { return c ? c->pair_octaves : 0; }
+int sg_last_tail_octave(const sg_ctx *c) { return c ? c->tail_octave : 0; }
 
 int sg_level_dims(const sg_ctx *c, int octave, int *rows, int *cols)
 {

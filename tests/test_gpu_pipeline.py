@@ -436,3 +436,47 @@ print("pair ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0 and "pair ok" in r.stdout, r.stderr[-3000:] + r.stdout[-500:]
+
+
+def test_pyramid_tail_launch_and_level_by_level_agree(oracle, gpu64):
+    """The smallest octaves come from one launch that keeps their planes in LDS (pyr_tail_k).  In this process the
+    launch is on (default): it must have been taken, second image of a batch included; in a process with
+    SIFTGPU_PYR_TAIL=0 the same octaves go level by level through the row / column kernels.  Both must give the
+    oracle's pyramid bit for bit, planes narrower than the widest kernel included."""
+    import subprocess
+    import sys
+    import sift_amd
+    img = oracle.vnoise5(640, 480, 21)
+    with sift_amd.SiftGPU(max_width=640, max_height=480, max_batch=2) as c:
+        c.extract(img)
+        assert 1 <= c.last_tail_octave() < c.last_octaves()
+        dbg = oracle.Debug(img)
+        for o in range(c.last_tail_octave(), dbg.octaves):
+            for l in range(6):
+                assert np.array_equal(c.read_level(o, l), dbg.gauss[o * 6 + l]), (o, l)
+        flipped = np.ascontiguousarray(img[::-1])
+        c.extract_batch(np.stack([img, flipped]), 8192)
+        dbg2 = oracle.Debug(flipped)
+        for o in range(dbg2.octaves):
+            for l in range(6):
+                assert np.array_equal(c.read_level(o, l, image=1), dbg2.gauss[o * 6 + l]), (o, l)
+    code = r'''
+import numpy as np, sift_amd
+from oracle import oracle as O
+for (w, h, seed) in [(200, 150, 3), (333, 211, 4), (64, 48, 5), (640, 480, 7)]:
+    img = sift_amd.vnoise5(w, h, seed)
+    dbg = O.Debug(img)
+    with sift_amd.SiftGPU(max_width=w, max_height=h) as c:
+        got = c.extract(img)
+        assert c.last_tail_octave() == c.last_octaves(), (w, h)
+        for o in range(dbg.octaves):
+            for l in range(6):
+                assert np.array_equal(c.read_level(o, l), dbg.gauss[o * 6 + l]), (w, h, o, l)
+        assert c.read_counters() == dbg.counters
+print("no tail ok")
+'''
+    import os
+    env = dict(os.environ, SIFTGPU_PYR_TAIL="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert r.returncode == 0 and "no tail ok" in r.stdout, r.stderr[-3000:] + r.stdout[-500:]

@@ -272,7 +272,14 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
                    size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec,
                    unsigned long long *counters, hipStream_t s)
 {
-    unsigned int blocks = feature_blocks(cap, B, 64, 256, env().ori_waves);
+    // Short lists (a frame alone, a small batch): one resident generation of waves (20 per compute unit) -- a keypoint
+    // list that fills the chip only a few times over is finished sooner by waves that stay and take several keypoints
+    // each than by waves that come and go; longer lists gain from more waves, which even out the differences between
+    // windows.  The list lengths are on the device; the capacity (about three times a natural image's count) stands in.
+    // (Measured per batch size at 1080p and for an 8K frame alone.)
+    const unsigned long long room = (unsigned long long)cap * (unsigned int)(B > 0 ? B : 1);
+    unsigned int blocks = feature_blocks(cap, B, room <= 500000ull ? 20 : (room <= 1000000ull ? 40 : 64), 256,
+                                         env().ori_waves);
     if (blocks == 0)
         return;
     dim3 g(blocks, B);
@@ -637,6 +644,17 @@ void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_str
                   int max_radius, int B, int prec, unsigned long long *counters, hipStream_t s)
 {
     unsigned int blocks = feature_blocks(cap, B, 384, 384, env().descr_waves);
+    // about four features per wave at least (the capacity is about two and a half times a natural image's count): with
+    // fewer, the set-up of a wave and the gaps between generations of waves cost more than the finer balance gains
+    // -- and whole generations (20 waves per compute unit are resident): a last generation of a few waves costs as much
+    // time as a full one
+    if (env().descr_waves <= 0 && blocks > cap / 10) {
+        const unsigned int gen = 20u * (unsigned int)env().n_cu, nb = (unsigned int)(B > 0 ? B : 1);
+        unsigned int total = cap / 10 * nb;
+        total = total > gen ? total - total % gen : gen; // at least the one generation that costs nothing extra
+        const unsigned int per_image = total / nb > 384u ? total / nb : 384u;
+        blocks = per_image < blocks ? per_image : blocks;
+    }
     if (blocks == 0)
         return;
     dim3 g(blocks, B);

@@ -261,8 +261,10 @@ static unsigned int feature_blocks(unsigned int cap, int B, unsigned int waves_p
     if (total_override > 0)
         total = (unsigned int)total_override;
     unsigned int blocks = total / (unsigned int)(B > 0 ? B : 1);
-    if (blocks < min_per_image) // large batches: a wave still takes no more than a few dozen entries of an image
+    if (blocks < min_per_image && total_override <= 0) // large batches: a wave still takes no more than a few dozen entries of an image
         blocks = min_per_image;
+    if (blocks == 0)
+        blocks = 1;
     return blocks < cap ? blocks : cap;
 }
 

@@ -139,6 +139,8 @@ void SiftSetVerbose(bool on);    // print the reference's progress lines (sift.c
 void SiftReleaseContext();       // free this thread's GPU context
 // Sift()/Sift_nointerval() calls of all threads share one context per device that runs up to max_batch images per
 // batch (whatever is waiting when the context falls idle; nobody waits for a batch to fill).  0 or 1: every thread
-// drives a context of its own (the default; the environment variable SIFT_GPU_BATCH sets another default).  Call it
-// while no Sift() call is running: it frees the shared contexts.
+// drives a context of its own (the default; the environment variable SIFT_GPU_BATCH sets another default).  There are
+// two such contexts per device, taken in turn (SIFT_GPU_LANES = 1..4 sets another number), so that one batch's
+// transfers overlap the other's kernels; a context whose batch size does not fit the device is created smaller.
+// Call it while no Sift() call is running: it frees the shared contexts.
 void SiftSetBatching(int max_batch);

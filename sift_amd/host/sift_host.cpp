@@ -249,8 +249,9 @@ public:
             }
             lk.unlock();
             int wb = -1;
+            std::vector<Request *> back; // requests the context turned out too small for: queued again
             try {
-                wb = execute(batch);
+                wb = execute(batch, back);
             } catch (...) { // out of host memory in the bookkeeping: the batch fails, the context stays usable
                 fail_all(batch, SG_E_NOMEM, "out of host memory");
                 for (Request *q : batch)
@@ -267,6 +268,7 @@ public:
             }
             for (Request *q : batch)
                 q->done = true;
+            queue_.insert(queue_.begin(), back.begin(), back.end());
             busy_ = false;
             cv_.notify_all();
         }
@@ -318,13 +320,19 @@ private:
         p.nointerval = ni;
         p.max_width = w > max_w_ ? w : max_w_;
         p.max_height = h > max_h_ ? h : max_h_;
-        p.max_batch = B_;
         p.device = device_;
         p.max_features = max_features_ > 0x7fffffff ? 0x7fffffff : (int)max_features_;
-        if (sg_create(&p, &ctx_) != SG_OK) {
+        // a batch of large images may not fit the device (an 8K frame takes 10 GB): fewer images per batch then
+        for (;;) {
+            p.max_batch = B_;
+            if (sg_create(&p, &ctx_) == SG_OK)
+                break;
             ctx_ = nullptr;
-            max_w_ = max_h_ = 0;
-            return false;
+            if (B_ <= 1) {
+                max_w_ = max_h_ = 0;
+                return false;
+            }
+            B_ = (B_ + 1) / 2;
         }
         max_w_ = p.max_width;
         max_h_ = p.max_height;
@@ -342,27 +350,47 @@ private:
     }
 
     // runs one batch; returns the wire buffer its results lie in (-1: none)
-    int execute(const std::vector<Request *> &batch)
+    int execute(std::vector<Request *> &batch, std::vector<Request *> &back)
     {
         const Request &h = *batch[0];
-        const int n = (int)batch.size();
         if (!make_context(h.w < 2 ? 2 : h.w, h.h < 2 ? 2 : h.h, h.sigma, h.nointerval, 0)) {
             fail_all(batch, SG_E_HIP, "sg_create failed (is a HIP device present? there is no CPU fallback)");
             return -1;
         }
+        auto trim = [&] { // the context for this image size came out smaller than the batch collected
+            if ((int)batch.size() > B_) {
+                back.insert(back.begin(), batch.begin() + B_, batch.end());
+                batch.resize((size_t)B_);
+            }
+        };
+        trim();
+        int n = (int)batch.size();
         std::vector<const uint8_t *> imgs(batch.size());
         for (int i = 0; i < n; i++)
             imgs[(size_t)i] = batch[(size_t)i]->px;
         std::vector<uint32_t> counts(batch.size());
         int rc = SG_OK;
-        for (int attempt = 0; attempt < 4; attempt++) {
+        for (int attempt = 0; attempt < 8; attempt++) {
             rc = sg_extract_batch_begin(ctx_, imgs.data(), n, h.w, h.h, h.ch, (size_t)h.w * h.ch, 1, counts.data());
+            if (rc == SG_E_NOMEM && B_ > 1) {
+                // the context fitted the device but left no room for the batch's transfer buffers: half the batch
+                sg_destroy(ctx_);
+                ctx_ = nullptr;
+                B_ = (B_ + 1) / 2;
+                if (!make_context(h.w, h.h, h.sigma, h.nointerval, 0))
+                    break;
+                trim();
+                n = (int)batch.size();
+                continue;
+            }
             if (rc != SG_E_CAPACITY)
                 break;
             size_t need = 0; // an image denser than the context was sized for: a larger context, and again
             if (sg_required_features(ctx_, &need) != SG_OK || need <= max_features_ ||
                 !make_context(h.w, h.h, h.sigma, h.nointerval, need))
                 break;
+            trim();
+            n = (int)batch.size();
         }
         if (rc != SG_OK) {
             fail_all(batch, rc, ctx_ ? sg_last_error(ctx_) : "");
@@ -428,7 +456,8 @@ private:
     std::condition_variable cv_;
     std::deque<Request *> queue_;
     bool busy_ = false;
-    const int device_, B_;
+    const int device_;
+    int B_; // images per batch: as asked for, halved while a context of that size does not fit the device
     sg_ctx *ctx_ = nullptr;
     int max_w_ = 0, max_h_ = 0, ni_ = -1;
     double sigma_ = 0;
@@ -440,7 +469,7 @@ private:
 
 std::atomic<int> g_batching(-1); // -1: not set yet (the environment decides on first use)
 std::mutex g_batchers_mutex;
-std::map<int, Batcher *> g_batchers; // per device; live until SiftSetBatching() drops them
+std::map<int, Batcher *> g_batchers; // per (device, lane); live until SiftSetBatching() drops them
 
 int batching()
 {
@@ -459,10 +488,24 @@ int batching()
     return b;
 }
 
+// Two shared contexts per device, taken in turn by the calls: while one batch is on the bus (images up, records
+// down) or between leaders, the other one's kernels keep the GPU busy.
+int lanes()
+{
+    static const int n = [] {
+        const char *e = std::getenv("SIFT_GPU_LANES");
+        const int v = e ? std::atoi(e) : 2;
+        return v < 1 ? 1 : (v > 4 ? 4 : v);
+    }();
+    return n;
+}
+std::atomic<unsigned int> g_next_lane(0);
+
 Batcher *batcher_for(int device, int max_batch)
 {
+    const int lane = (int)(g_next_lane.fetch_add(1) % (unsigned int)lanes());
     std::lock_guard<std::mutex> lk(g_batchers_mutex);
-    Batcher *&b = g_batchers[device];
+    Batcher *&b = g_batchers[device * 4 + lane];
     if (!b)
         b = new Batcher(device, max_batch);
     return b;

@@ -81,3 +81,13 @@ def test_threads_sharing_one_context_get_their_own_records():
     out = subprocess.run([exe, "shared", "320", "240", "12", "6", "8"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "shared ok: 12 threads x 6 calls" in out.stdout
+
+
+def test_shared_context_shrinks_its_batch_for_8k_frames():
+    """Two shared contexts of 16 8K frames each do not fit one GPU (an 8K frame takes 10 GB): the layer must come down
+    to batch sizes that fit, queue the requests it had collected beyond them again, and still return every caller's
+    own records."""
+    exe = _need("sift_host_check")
+    out = subprocess.run([exe, "shared", "7680", "4320", "5", "1", "16"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "shared ok: 5 threads x 1 calls" in out.stdout

@@ -198,8 +198,8 @@ def host_api_throughput(W, H, dev_index, cpu_threads):
         r = run(0)
         r["what"] = ("Sift() on host images, 1120-byte records appended to a host vector; sift_ms_single = one thread, "
                      "one call at a time; images_per_s = %d host threads, one context each, one GPU; "
-                     "images_per_s_shared_context = the same threads through one shared context of up to 16 images "
-                     "per batch (SiftSetBatching(16))" % threads)
+                     "images_per_s_shared_context = the same threads through the shared batching contexts (two per "
+                     "device, up to 16 images per batch: SiftSetBatching(16))" % threads)
         r["images_per_s_shared_context"] = run(16)["images_per_s"]
         return r
     except Exception as e:

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the SIFT extraction path on MI355X.
 
-Metric (BASELINE.json): 1080p images/s (keypoints + descriptors), whole job over N GPUs, plus the HBM
+Metric: 1080p images/s (keypoints + descriptors), whole job over N GPUs, plus the HBM
 rate of the blur kernels.  Workload: 1920x1080 synthetic frames (5-octave value noise, seeds 1000...),
 resident in HBM before the timed region; one step = one batch of `--batch` frames through the whole path
 (gray/upsample/blur, Gaussian pyramid, fused DoG+extrema, refinement, orientation, descriptors, scale
-ordering, 144-byte packed features).  With the defaults 4 steps x 64 frames = the 256-frame batch config.
+ordering, 144-byte packed features).  With the defaults 4 steps x 256 frames (the 256-frame batch configuration).
 
   python bench.py --gpus 1 --steps 4 --warmup 2
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \

@@ -98,28 +98,8 @@ __device__ __forceinline__ double sg_div_sum(double n, double d)
     return n * r;
 }
 
-// sg_atan_split with that division and the odd series cut after u^11/11 (|u| <= tan(pi/32): truncation below 7e-15)
-__device__ __forceinline__ double sg_atan_split_sum(double mn, double mx, const double2 *centres, double &k_term)
-{
-    unsigned int koff = mn > 0.09849140335716425 * mx ? 16u : 0u;
-    koff = mn > 0.30334668360734239 * mx ? 32u : koff;
-    koff = mn > 0.53451113595079158 * mx ? 48u : koff;
-    koff = mn > 0.82067879082866024 * mx ? 64u : koff;
-    const double2 ck = *reinterpret_cast<const double2 *>(reinterpret_cast<const char *>(centres) + koff);
-    k_term = ck.y;
-    const double num = __builtin_fma(-ck.x, mx, mn);
-    const double den = fmax(__builtin_fma(ck.x, mn, mx), 1e-300);
-    const double u = sg_div_sum(num, den);
-    const double z = u * u;
-    double p = -1.0 / 11.0;
-    p = sg_fma3(p, z, 1.0 / 9.0);
-    p = sg_fma3(p, z, -1.0 / 7.0);
-    p = sg_fma3(p, z, 1.0 / 5.0);
-    p = sg_fma3(p, z, -1.0 / 3.0);
-    return __builtin_fma(u * z, p, u);
-}
-
-// The same split with the centre picked from a 35-entry table by the single-precision ratio: entry i serves
+// sg_atan_split with that division, the odd series cut after u^11/11, and the centre picked from a 35-entry table
+// by the single-precision ratio: entry i serves
 // mn/mx in [i/33, (i+1)/33) and holds (tan(k pi/16), k/4) for the k nearest to atan((i + 1/2)/33), so that
 // |u| <= tan(pi/32 + 1/66) = 0.114 and the series' truncation stays below 5e-14.  Two conversions, one v_rcp_f32, two
 // single-precision products and one LDS read replace four double products, four compares and four selects.  A zero
@@ -175,21 +155,6 @@ __device__ __forceinline__ void sg_atan_centres_fill(double2 *centres, int lane,
         e.y = radians ? rad : 0.25 * lane;
         centres[lane] = e;
     }
-}
-
-// atan2(y, x) in radians to about 1e-14, from a table filled by sg_atan_lut_fill(lut, lane, true)
-__device__ __forceinline__ double sg_atan2_lut(double y, double x, const double2 *lut)
-{
-    const double ax = fabs(x), ay = fabs(y);
-    const double mx = ax > ay ? ax : ay, mn = ax > ay ? ay : ax;
-    double off;
-    const double a = sg_atan_split_lut(mn, mx, lut, off);
-    double r = off + a;
-    if (ay > ax)
-        r = 1.5707963267948966 - r;
-    if (x < 0.0)
-        r = 3.1415926535897932 - r;
-    return y < 0.0 ? -r : r;
 }
 
 // atan2(y, x) in radians; centres filled with radians = true.  atan2(0,0) = 0 like the C library.

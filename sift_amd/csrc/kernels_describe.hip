@@ -495,7 +495,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                 unsigned int rc; // (row << 8) | column inside the window (packed), or the column alone (wide windows)
                 T nl, nr, nu, nd;
             };
+            // Every fetch is issued unconditionally (an entry index beyond the list takes the last entry's address
+            // again): loads that sit in no branch let the wait in front of a slot's first use be counted exactly,
+            // so that the two younger slots' loads stay in flight across it.
+            const int last_entry = count - 1;
             auto fetch = [&](int e, Sample &sm) {
+                e = min(e, last_entry);
                 unsigned int r, c;
                 if (packed) {
                     sm.rc = queue[e];
@@ -513,7 +518,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                 sm.nu = *reinterpret_cast<const T *>(gb_up + (size_t)off);
                 sm.nd = *reinterpret_cast<const T *>(gb_dn + (size_t)off);
             };
-            auto process = [&](const Sample &sm) {
+            auto process = [&](const Sample &sm, bool listed) {
                 const unsigned int sr = packed ? sm.rc >> 8 : (unsigned int)big_row, sc = packed ? sm.rc & 255u : sm.rc;
                 const int i = (int)sr - radius, jj = (int)sc - radius;
                 const double dx = (double)sm.nr - (double)sm.nl;
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                 // truncation is the floor and the cell index is never negative
                 const double xs = __builtin_fma(cs, (double)jj, __builtin_fma(-ss, (double)i, 2.5));
                 const double ys = __builtin_fma(ss, (double)jj, __builtin_fma(cs, (double)i, 2.5));
-                if (xs > 0.0 && xs < 5.0 && ys > 0.0 && ys < 5.0) {
+                if (listed && xs > 0.0 && xs < 5.0 && ys > 0.0 && ys < 5.0) {
                     const double grad_mag = sg_sqrt_sum(__builtin_fma(dx, dx, dy * dy));
                     // obin = ((pi - atan2(dy,dx)) - ori) * 8/(2 pi) = obin_c - atan2(dy,dx) in units of pi/4; the
                     // histogram index below wraps by itself, so the angle is not brought into [0, 2 pi) first
@@ -575,26 +580,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
             // trips before the slot is used.  One trip of the five resident waves of a SIMD is shorter than a gather's
             // round trip through the memory system, so a single trip of distance leaves the SIMD waiting.
             trips += (unsigned int)((count + 63) >> 6);
-            Sample s0, s1, s2;
-            s0.rc = s1.rc = s2.rc = 0;
-            s0.nl = s0.nr = s0.nu = s0.nd = s1.nl = s1.nr = s1.nu = s1.nd = s2.nl = s2.nr = s2.nu = s2.nd = (T)0;
-            if (lane < count)
+            if (count > 0) {
+                Sample s0, s1, s2;
                 fetch(lane, s0);
-            if (lane + 64 < count)
                 fetch(lane + 64, s1);
-            for (int e = lane; e < count; e += 192) {
-                if (e + 128 < count)
+                for (int base = 0; base < count; base += 192) { // count is the wave's: a uniform loop
+                    const int e = base + lane;
                     fetch(e + 128, s2);
-                process(s0);
-                if (e + 64 < count) {
-                    if (e + 192 < count)
-                        fetch(e + 192, s0);
-                    process(s1);
-                    if (e + 128 < count) {
-                        if (e + 256 < count)
-                            fetch(e + 256, s1);
-                        process(s2);
-                    }
+                    process(s0, e < count);
+                    fetch(e + 192, s0);
+                    process(s1, e + 64 < count);
+                    fetch(e + 256, s1);
+                    process(s2, e + 128 < count);
                 }
             }
             wave_lds_fence();

@@ -5,8 +5,8 @@
 
 Compiles sift_amd/csrc/kernels_describe.hip to assembly with the library's own flags, finds in descr_k<double,false>
 and orient_k<double,false> the innermost loops that hold the LDS histogram adds (ds_add_u64 / ds_add_f64) and counts their
-instructions by class.  The descriptor loop takes three 64-sample trips per pass (three sample slots in rotation), so
-its counts are divided by three; the orientation kernel has two forms of its loop (windows inside the plane, the common one, and
+instructions by class.  The descriptor loop takes two 64-sample trips per pass (two sample slots in rotation), so
+its counts are divided by two; the orientation kernel has two forms of its loop (windows inside the plane, the common one, and
 windows that cross the border): the shorter one is reported.  Branches inside a loop make these counts upper bounds
 of what one trip executes.  bench.py multiplies them by the measured trip counts to price the kernels against the
 vector issue rate (`valu_roofline`)."""
@@ -77,11 +77,11 @@ def main():
         subprocess.check_call(["/opt/rocm/bin/hipcc"] + FLAGS + [SRC, "-o", asm], stderr=subprocess.DEVNULL)
         lines = open(asm).read().split("\n")
     res = {"_source": "sift_amd/csrc/kernels_describe.hip", "_flags": " ".join(FLAGS[:4])}
-    # descr_k<double,false>: the loop with 24 histogram adds (three trips of 8)
+    # descr_k<double,false>: the loop with 16 histogram adds (two trips of 8)
     body = kernel_body(lines, "_ZN2sg7descr_kIdLb0EE")
-    cand = [l for l in loops_with_hist_adds(body) if l[1] == 24]
+    cand = [l for l in loops_with_hist_adds(body) if l[1] == 16]
     n, adds, seg = min(cand, key=lambda t: t[0])
-    res["descr_k<double,false>"] = dict(count(seg, 3.0), trips_per_loop_pass=3)
+    res["descr_k<double,false>"] = dict(count(seg, 2.0), trips_per_loop_pass=2)
     body = kernel_body(lines, "_ZN2sg8orient_kIdLb0EE")
     cand = [l for l in loops_with_hist_adds(body) if l[1] == 1]
     n, adds, seg = min(cand, key=lambda t: t[0])

@@ -576,22 +576,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                     }
                 }
             };
-            // Three sample slots in rotation (the loop body is written three times): the loads of a slot are issued two
-            // trips before the slot is used.  One trip of the five resident waves of a SIMD is shorter than a gather's
-            // round trip through the memory system, so a single trip of distance leaves the SIMD waiting.
+            // Two sample slots in rotation (the loop body is written twice): the loads of a slot are issued while the
+            // other slot is processed, and the wait in front of a slot's use leaves the younger slot's four loads in
+            // flight (vmcnt(4)).  (A third slot, two trips of distance, was measured 1.5 % slower.)
             trips += (unsigned int)((count + 63) >> 6);
             if (count > 0) {
-                Sample s0, s1, s2;
+                Sample s0, s1;
                 fetch(lane, s0);
-                fetch(lane + 64, s1);
-                for (int base = 0; base < count; base += 192) { // count is the wave's: a uniform loop
+                for (int base = 0; base < count; base += 128) { // count is the wave's: a uniform loop
                     const int e = base + lane;
-                    fetch(e + 128, s2);
+                    fetch(e + 64, s1);
                     process(s0, e < count);
-                    fetch(e + 192, s0);
+                    fetch(e + 128, s0);
                     process(s1, e + 64 < count);
-                    fetch(e + 256, s1);
-                    process(s2, e + 128 < count);
                 }
             }
             wave_lds_fence();

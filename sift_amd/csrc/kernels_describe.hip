@@ -1,6 +1,7 @@
 // kernels_describe.hip -- orientation assignment, 4x4x8 descriptors, scale ordering and output packing
 // for gfx950.  All histogram arithmetic is double precision whatever the pyramid's storage type.
 #include "sg_internal.h"
+#include "sg_dd.h"
 #include "sg_math.h"
 
 #include <stddef.h>
@@ -56,6 +57,9 @@ __device__ __forceinline__ void lds_add_fixed(unsigned long long *p, double a, d
 // maximum (sift.cpp:1231-1240) and the peak test with parabolic refinement (sift.cpp:1280-1307) run on
 // lanes 0..35.  BIG (chosen on the host from the largest radius the parameters allow) adds the path for
 // windows of radius 64 and more, whose weights do not fit the table.
+// Kept out of line: it runs for a handful of samples per frame and must not cost the window walk any registers.
+__device__ __noinline__ double atan2_correctly_rounded(double y, double x) { return sg_atan2_cr(y, x); }
+
 constexpr int kOriCopies = 4;
 constexpr int kOriCopyStride = 66; // doubles; 64 + 2, so that the copies start 4 banks apart
 constexpr int kOriTab = 64;
@@ -183,8 +187,14 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
                         const double num = kOriBins * (SG_PI - ori);
                         double quo = num * (1.0 / PI2);
                         const bool near_half = fabs(fabs(quo - rint(quo)) - 0.5) < 1e-9;
-                        if (__ballot(near_half)) // wave-uniform, so that the division is skipped and not merely masked
-                            quo = near_half ? num / PI2 : quo;
+                        if (__ballot(near_half)) { // wave-uniform, so that this is skipped and not merely masked
+                            // Next to a bin boundary (gradients along a diagonal, which symmetric structure produces
+                            // to the last bit or an ulp off it) the bin hangs on the last bit of atan2: there the angle
+                            // is evaluated correctly rounded, as the C library does it but for one argument in two
+                            // thousand, and the quotient by the reference's own division.
+                            if (near_half)
+                                quo = (kOriBins * (SG_PI - atan2_correctly_rounded(dy, dx))) / PI2;
+                        }
                         int bin = (int)rint(quo);
                         bin = bin < kOriBins ? bin : 0;
                         lds_add(&hc[bin], mag * weight);

@@ -5,6 +5,7 @@
 // out in the reference's raster order (octave, layer, y, x), so expanding the set bits in word order
 // reproduces the emission order of the reference's nested loops (sift/sift.cpp:925-938) without a sort.
 #include "sg_internal.h"
+#include "sg_dd.h"
 #include "sg_lds_dma.h"
 #include <stdlib.h>
 
@@ -879,8 +880,11 @@ __global__ __launch_bounds__(256) void refine_k(OctaveTab tab, const unsigned in
                         rec.dx = ((x + off[0]) * p2) / 2;
                         rec.dy = ((y + off[1]) * p2) / 2;
                         double intvl = interval + off[2];
-                        rec.scale = (sigma * pow(2.0, o + intvl / 3)) / 2;
-                        rec.oscale = sigma * pow(2.0, intvl / 3);
+                        // scale is the sort key of the output: the last bit of pow() orders features whose scales lie
+                        // an ulp apart, so 2^y is evaluated correctly rounded, which is what the C library returns but
+                        // for one argument in a thousand
+                        rec.scale = (sigma * sg_exp2_cr(o + intvl / 3)) / 2;
+                        rec.oscale = sigma * sg_exp2_cr(intvl / 3);
                         rec.val = val;
                     }
                 }

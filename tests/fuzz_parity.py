@@ -1,0 +1,89 @@
+#!/usr/bin/env python3
+"""Random sizes, generators and seeds through the whole path, every case against the CPU oracle (not collected by
+pytest; run by hand on a GPU box):  python tests/fuzz_parity.py [cases] [first seed]
+
+Per case: detection counters, refined keypoints bit for bit, feature list (integer fields, descriptor bins) equal,
+orientation within 1e-9 rad; both detectors (3x3x3 and in-layer); every tenth case also as the second frame of a
+batch.  Prints one line per failure and a summary; exit status 1 on any failure."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import sift_amd  # noqa: E402
+from sift_amd import synth  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def make(rng, k):
+    w, h = int(rng.integers(8, 420)), int(rng.integers(8, 320))
+    seed = int(rng.integers(1, 1 << 30))
+    kind = k % 7
+    if kind == 0:
+        return "vnoise5", synth.vnoise5(w, h, seed)
+    if kind == 1:
+        return "checker", synth.checkerboard(w, h, int(rng.integers(2, 24)), int(rng.integers(0, 100)), int(rng.integers(150, 256)))
+    if kind == 2:
+        return "edges", synth.step_edges(w, h, seed, n=int(rng.integers(3, 60)))
+    if kind == 3:
+        return "blobs", synth.blobs(w, h, seed, n=int(rng.integers(3, 80)))
+    if kind == 4:
+        return "blocks", synth.saturated_blocks(w, h, seed)
+    if kind == 5:
+        return "white", synth.white_noise(w, h, seed)
+    img = synth.vnoise5(w, h, seed).astype(np.int32) + synth.step_edges(w, h, seed + 1).astype(np.int32) // 3
+    return "mixed", np.clip(img, 0, 255).astype(np.uint8)
+
+
+def same(a, b, fields):
+    return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in fields)
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+    ctx = {ni: sift_amd.SiftGPU(max_width=420, max_height=320, max_batch=2, max_features=60000, nointerval=bool(ni))
+           for ni in (0, 1)}
+    bad = 0
+    feats_total = 0
+    for k in range(n):
+        name, img = make(rng, k)
+        h, w = img.shape[:2]
+        ni = k % 3 == 2
+        c = ctx[int(ni)]
+        try:
+            ref, n_kp, ctr, _ = O.sift(img, nointerval=ni)
+            got = c.extract(img, cap=120000)
+            problems = []
+            if tuple(c.read_counters()) != tuple(ctr):
+                problems.append("counters %s != %s" % (c.read_counters(), ctr))
+            if not same(got, ref, ("octave", "interval", "x", "y", "dx", "dy", "offset_x", "offset_y", "offset_interval", "val")):
+                problems.append("feature list (%d vs %d)" % (len(got), len(ref)))
+            elif len(ref):
+                if not np.array_equal(got["descriptor"], ref["descriptor"]):
+                    problems.append("descriptor bins differ in %d features" % int((got["descriptor"] != ref["descriptor"]).any(axis=1).sum()))
+                d = np.abs(got["ori"] - ref["ori"])
+                if np.minimum(d, 2 * np.pi - d).max() > 1e-9:
+                    problems.append("orientation off by %g" % np.minimum(d, 2 * np.pi - d).max())
+                if not np.allclose(got["scale"], ref["scale"], rtol=1e-13, atol=0):
+                    problems.append("scale")
+            if k % 10 == 0 and not problems:
+                two = c.extract_batch(np.stack([img[::-1].copy(), img]), 60000)[1]
+                if len(two) != len(ref) or (len(ref) and not np.array_equal(two["desc"], ref["descriptor"].astype(np.uint8))):
+                    problems.append("second frame of a batch differs")
+            feats_total += len(ref)
+        except Exception as e:  # report and go on
+            problems = ["exception %r" % (e,)]
+        if problems:
+            bad += 1
+            print("FAIL case %d %s %dx%d nointerval=%d: %s" % (k, name, w, h, ni, "; ".join(problems)), flush=True)
+        if k % 25 == 24:
+            print("... %d cases, %d failures, %d features compared" % (k + 1, bad, feats_total), flush=True)
+    print("fuzz: %d cases, %d failures, %d features compared" % (n, bad, feats_total))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Random sizes, generators and seeds through the whole path, every case against the CPU oracle (not collected by
-pytest; run by hand on a GPU box):  python tests/fuzz_parity.py [cases] [first seed]
+pytest; run by hand on a GPU box):  python tests/fuzz_parity.py [cases] [first seed] [max width] [max height]
 
 Per case: detection counters, refined keypoints bit for bit, feature list (integer fields, descriptor bins) equal,
 orientation within 1e-9 rad; both detectors (3x3x3 and in-layer); every tenth case also as the second frame of a
@@ -17,8 +17,11 @@ from sift_amd import synth  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
+MAX_W, MAX_H = 420, 320
+
+
 def make(rng, k):
-    w, h = int(rng.integers(8, 420)), int(rng.integers(8, 320))
+    w, h = int(rng.integers(8, MAX_W)), int(rng.integers(8, MAX_H))
     seed = int(rng.integers(1, 1 << 30))
     kind = k % 7
     if kind == 0:
@@ -42,9 +45,13 @@ def same(a, b, fields):
 
 
 def main():
+    global MAX_W, MAX_H
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-    ctx = {ni: sift_amd.SiftGPU(max_width=420, max_height=320, max_batch=2, max_features=60000, nointerval=bool(ni))
+    if len(sys.argv) > 4:
+        MAX_W, MAX_H = int(sys.argv[3]), int(sys.argv[4])
+    ctx = {ni: sift_amd.SiftGPU(max_width=MAX_W, max_height=MAX_H, max_batch=2, max_features=MAX_W * MAX_H // 2,
+                                nointerval=bool(ni))
            for ni in (0, 1)}
     bad = 0
     feats_total = 0
@@ -55,7 +62,7 @@ def main():
         c = ctx[int(ni)]
         try:
             ref, n_kp, ctr, _ = O.sift(img, nointerval=ni)
-            got = c.extract(img, cap=120000)
+            got = c.extract(img, cap=MAX_W * MAX_H)
             problems = []
             if tuple(c.read_counters()) != tuple(ctr):
                 problems.append("counters %s != %s" % (c.read_counters(), ctr))
@@ -70,7 +77,7 @@ def main():
                 if not np.allclose(got["scale"], ref["scale"], rtol=1e-13, atol=0):
                     problems.append("scale")
             if k % 10 == 0 and not problems:
-                two = c.extract_batch(np.stack([img[::-1].copy(), img]), 60000)[1]
+                two = c.extract_batch(np.stack([img[::-1].copy(), img]), MAX_W * MAX_H // 2)[1]
                 if len(two) != len(ref) or (len(ref) and not np.array_equal(two["desc"], ref["descriptor"].astype(np.uint8))):
                     problems.append("second frame of a batch differs")
             feats_total += len(ref)

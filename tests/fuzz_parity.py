@@ -3,7 +3,7 @@
 pytest; run by hand on a GPU box):  python tests/fuzz_parity.py [cases] [first seed] [max width] [max height]
 
 Per case: detection counters, refined keypoints bit for bit, feature list (integer fields, descriptor bins) equal,
-orientation within 1e-9 rad; both detectors (3x3x3 and in-layer); every tenth case also as the second frame of a
+orientation within 1e-9 rad; both detectors (3x3x3 and in-layer); every eighth case at another base sigma; every tenth case also as the second frame of a
 batch.  Prints one line per failure and a summary; exit status 1 on any failure."""
 import os
 import sys
@@ -50,18 +50,24 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     if len(sys.argv) > 4:
         MAX_W, MAX_H = int(sys.argv[3]), int(sys.argv[4])
-    ctx = {ni: sift_amd.SiftGPU(max_width=MAX_W, max_height=MAX_H, max_batch=2, max_features=MAX_W * MAX_H // 2,
-                                nointerval=bool(ni))
-           for ni in (0, 1)}
+    ctx = {}
+
+    def context(ni, sigma):
+        if (ni, sigma) not in ctx:
+            ctx[(ni, sigma)] = sift_amd.SiftGPU(max_width=MAX_W, max_height=MAX_H, max_batch=2,
+                                                max_features=MAX_W * MAX_H // 2, nointerval=bool(ni), sigma=sigma)
+        return ctx[(ni, sigma)]
+
     bad = 0
     feats_total = 0
     for k in range(n):
         name, img = make(rng, k)
         h, w = img.shape[:2]
         ni = k % 3 == 2
-        c = ctx[int(ni)]
+        sigma = 1.6 if k % 8 else (1.3 if k % 16 else 2.2)  # every eighth case at another base sigma
+        c = context(int(ni), sigma)
         try:
-            ref, n_kp, ctr, _ = O.sift(img, nointerval=ni)
+            ref, n_kp, ctr, _ = O.sift(img, sigma=sigma, nointerval=ni)
             got = c.extract(img, cap=MAX_W * MAX_H)
             problems = []
             if tuple(c.read_counters()) != tuple(ctr):
@@ -85,7 +91,7 @@ def main():
             problems = ["exception %r" % (e,)]
         if problems:
             bad += 1
-            print("FAIL case %d %s %dx%d nointerval=%d: %s" % (k, name, w, h, ni, "; ".join(problems)), flush=True)
+            print("FAIL case %d %s %dx%d nointerval=%d sigma=%g: %s" % (k, name, w, h, ni, sigma, "; ".join(problems)), flush=True)
         if k % 25 == 24:
             print("... %d cases, %d failures, %d features compared" % (k + 1, bad, feats_total), flush=True)
     print("fuzz: %d cases, %d failures, %d features compared" % (n, bad, feats_total))

@@ -43,7 +43,8 @@ def test_counters_and_keypoints(case):
     assert np.allclose(kps["octave_scale"], ref["octave_scale"], rtol=1e-14, atol=0)
     # 2^y is evaluated correctly rounded on the device; the C library's pow() is too, but for about one argument in a
     # thousand: bit-equal scales but for a handful
-    assert (kps["scale"] == ref["scale"]).mean() > 0.99 and (kps["octave_scale"] == ref["octave_scale"]).mean() > 0.99
+    allowed = max(2, len(ref) // 200)
+    assert (kps["scale"] != ref["scale"]).sum() <= allowed and (kps["octave_scale"] != ref["octave_scale"]).sum() <= allowed
 
 
 def test_features_unsorted(case):

@@ -80,7 +80,8 @@ typedef struct sg_params {
                           sift.cpp:870,886,1325,1613, so other values are inconsistent there) */
     int precision;     /* sg_precision */
     int nointerval;    /* 0: 3x3x3 extremum test (Sift); 1: in-layer 3x3 test (Sift_nointerval) */
-    int max_width;     /* largest input image the context is sized for */
+    int max_width;     /* largest input image the context is sized for; the upsampled base plane must stay below
+                          4 GB (about 134 megapixels of input with the double pyramid): SG_E_UNSUPPORTED beyond */
     int max_height;
     int max_batch;     /* images processed per sg_extract_batch* call */
     int max_features;  /* per-image feature capacity; 0 = derived from the image size */

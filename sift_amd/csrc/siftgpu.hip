@@ -909,6 +909,16 @@ int sg_create(const sg_params *p, sg_ctx **out)
         return SG_E_INVALID; // sigma <= 2*INIT_SIGMA makes the initial blur's sigma imaginary (sift.cpp:343)
     if (p->precision != SG_F64 && p->precision != SG_F32)
         return SG_E_INVALID;
+    {
+        // The keypoint kernels address a pixel of a pyramid level by a 32-bit byte offset from the level's first pixel:
+        // the base plane (2W x 2H elements of the pyramid's type, rows padded to 4 elements) must stay below 4 GB,
+        // i.e. about 134 megapixels of input in double precision (an 8K frame has 33).
+        const unsigned long long base_bytes = 2ull * (unsigned long long)p->max_height *
+                                              (unsigned long long)((2ll * p->max_width + 3) & ~3ll) *
+                                              (p->precision == SG_F64 ? 8ull : 4ull);
+        if (p->max_width > (1 << 29) || p->max_height > (1 << 29) || base_bytes >= (1ull << 32))
+            return SG_E_UNSUPPORTED;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device < 0 || p->device >= ndev)
         return SG_E_HIP;

@@ -144,6 +144,21 @@ def test_no_cpu_fallback_without_device():
         sift_amd.SiftGPU()
 
 
+def test_parameter_limits_are_reported_before_any_device_work():
+    """Argument checks of sg_create that need no device: an image size whose base plane would pass 4 GB (the keypoint
+    kernels' 32-bit pixel offsets), intervals other than 3, a base sigma of 1 or less."""
+    import sift_amd
+    from sift_amd import api
+    for kw, want in (({"max_width": 16384, "max_height": 8192}, api.SG_E_UNSUPPORTED),
+                     ({"max_width": 40000, "max_height": 40000}, api.SG_E_UNSUPPORTED),
+                     ({"intervals": 4}, api.SG_E_UNSUPPORTED),
+                     ({"sigma": 1.0}, api.SG_E_INVALID),
+                     ({"max_batch": 0}, api.SG_E_INVALID)):
+        with pytest.raises(sift_amd.SiftGpuError) as e:
+            sift_amd.SiftGPU(**kw)
+        assert e.value.status == want, kw
+
+
 def test_match_known_answer(oracle):
     """The demo's matching loop (sift/源.cpp:88-156) on hand-made descriptors."""
     import numpy as np

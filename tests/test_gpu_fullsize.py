@@ -185,3 +185,34 @@ def test_1080p_batch256_equals_single(oracle):
             c.free(p)
         big.close()
         one.close()
+
+
+def test_frame_next_to_the_size_limit_equals_its_crop_locally(oracle):
+    """15360x8640 input: the base plane has 4.25e9 bytes, just under the 4 GB the 32-bit pixel offsets of the keypoint
+    kernels reach (larger sizes are refused).  No oracle at this size; instead the bottom 2048 rows are run again as
+    an image of their own: away from the cut (the blurs are local) the same features must come out, with equal integer
+    coordinates, offsets and descriptor bins -- which they only do if every address up to the last row is right."""
+    import sift_amd
+    W, H, CROP = 15360, 8640, 2048
+    img = oracle.vnoise5(W, H, 77)
+    top = H - CROP  # a multiple of 64: the octaves' sampling grids of frame and crop coincide
+    assert top % 64 == 0
+    with sift_amd.SiftGPU(max_width=W, max_height=H) as c:
+        full = c.extract(img, cap=1600000)
+        crop = c.extract(np.ascontiguousarray(img[top:]), cap=500000)
+    assert len(full) > 1300000 and (np.diff(full["scale"]) >= 0).all()
+    # features of octaves 0..2 whose windows stay 400 input pixels below the cut
+    def pick(f, y0):
+        m = (f["octave"] <= 2) & (f["dy"] > y0 + 400)
+        f = f[m]
+        order = np.lexsort((f["ori"], f["x"], f["y"], f["interval"], f["octave"]))
+        return f[order]
+    a, b = pick(full, top), pick(crop, 0)
+    assert len(a) == len(b) > 250000
+    assert np.array_equal(a["x"], b["x"]) and np.array_equal(a["octave"], b["octave"])
+    assert np.array_equal(a["y"], b["y"] + (top * 2 >> a["octave"]))  # y is in octave pixels of the doubled image
+    for f in ("offset_x", "offset_y", "offset_interval", "scale", "val", "dx"):
+        assert np.array_equal(a[f], b[f]), f
+    assert np.abs(a["dy"] - (b["dy"] + top)).max() < 1e-9  # (y + offset) rounds once, with y counted from another row
+    assert np.abs(a["ori"] - b["ori"]).max() < 1e-9
+    assert np.array_equal(a["descriptor"], b["descriptor"])

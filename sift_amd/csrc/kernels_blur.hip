@@ -16,6 +16,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 
 namespace sg {
@@ -1459,11 +1460,24 @@ template <typename T>
 static bool tail_dispatch(const OctaveTab &tab, int first, int B, const double *const *taps, const int *ntaps,
                           hipStream_t s)
 {
-    static bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&pyr_tail_k<T>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)kTailLdsBytes) == hipSuccess;
-    if (!attr_ok) {
-        (void)hipGetLastError();
+    // more dynamic LDS than the default limit: allowed per device, once (0 not tried yet, 1 allowed, 2 refused)
+    static unsigned char allowed[64] = {0};
+    static std::mutex allowed_mutex;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
         return false;
+    {
+        std::lock_guard<std::mutex> lk(allowed_mutex);
+        if (allowed[dev] == 0) {
+            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&pyr_tail_k<T>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                (int)kTailLdsBytes) == hipSuccess;
+            if (!ok)
+                (void)hipGetLastError();
+            allowed[dev] = ok ? 1 : 2;
+        }
+        if (allowed[dev] != 1)
+            return false;
     }
     TailTaps<T> tt;
     for (int l = 0; l < kLevels - 1; l++) {

@@ -60,8 +60,11 @@ def main():
 
     bad = 0
     feats_total = 0
+    only = os.environ.get("FUZZ_ONLY")  # one case number: the others are generated (the sequence stays) but not run
     for k in range(n):
         name, img = make(rng, k)
+        if only is not None and k != int(only):
+            continue
         h, w = img.shape[:2]
         ni = k % 3 == 2
         sigma = 1.6 if k % 8 else (1.3 if k % 16 else 2.2)  # every eighth case at another base sigma
@@ -74,6 +77,21 @@ def main():
                 problems.append("counters %s != %s" % (c.read_counters(), ctr))
             if not same(got, ref, ("octave", "interval", "x", "y", "dx", "dy", "offset_x", "offset_y", "offset_interval", "val")):
                 problems.append("feature list (%d vs %d)" % (len(got), len(ref)))
+                if only is not None and len(got) == len(ref):
+                    fields = ("octave", "interval", "x", "y", "dx", "dy", "offset_x", "offset_y", "offset_interval", "val")
+                    diff = np.zeros(len(ref), bool)
+                    for f in fields:
+                        diff |= got[f] != ref[f]
+                    ka = np.lexsort((np.round(ref["ori"], 6), ref["x"], ref["y"], ref["interval"], ref["octave"]))
+                    kb = np.lexsort((np.round(got["ori"], 6), got["x"], got["y"], got["interval"], got["octave"]))
+                    ra, gb = ref[ka], got[kb]
+                    print("    as sets: integer fields equal %s, descriptors equal %s, scales differing in the last bit: %d"
+                          % (all(np.array_equal(ra[f], gb[f]) for f in ("octave", "interval", "x", "y")),
+                             np.array_equal(ra["descriptor"], gb["descriptor"]), int((ra["scale"] != gb["scale"]).sum())))
+                    for j in np.nonzero(diff)[0][:8]:
+                        print("   ", j, "ref", [ref[f][j] for f in ("octave", "interval", "x", "y")], ref["scale"][j].hex(),
+                              ref["ori"][j], "| got", [got[f][j] for f in ("octave", "interval", "x", "y")],
+                              got["scale"][j].hex(), got["ori"][j])
             elif len(ref):
                 if not np.array_equal(got["descriptor"], ref["descriptor"]):
                     problems.append("descriptor bins differ in %d features" % int((got["descriptor"] != ref["descriptor"]).any(axis=1).sum()))

@@ -4,7 +4,7 @@ pytest; run by hand on a GPU box):  python tests/fuzz_parity.py [cases] [first s
 
 Per case: detection counters, refined keypoints bit for bit, feature list (integer fields, descriptor bins) equal,
 orientation within 1e-9 rad; both detectors (3x3x3 and in-layer); every eighth case at another base sigma; every tenth case also as the second frame of a
-batch.  Prints one line per failure and a summary; exit status 1 on any failure."""
+batch; every fifth case's features matched against the previous case's (ratio test), equal match lists.  Prints one line per failure and a summary; exit status 1 on any failure."""
 import os
 import sys
 
@@ -60,6 +60,8 @@ def main():
 
     bad = 0
     feats_total = 0
+    prev = None
+    matched = [0]
     only = os.environ.get("FUZZ_ONLY")  # one case number: the others are generated (the sequence stays) but not run
     for k in range(n):
         name, img = make(rng, k)
@@ -104,6 +106,16 @@ def main():
                 two = c.extract_batch(np.stack([img[::-1].copy(), img]), MAX_W * MAX_H // 2)[1]
                 if len(two) != len(ref) or (len(ref) and not np.array_equal(two["desc"], ref["descriptor"].astype(np.uint8))):
                     problems.append("second frame of a batch differs")
+            # every fifth case: the matcher on this case's and the previous checked case's features (checkerboards
+            # give many equal distances: first index wins)
+            if k % 5 == 0 and prev is not None and len(ref) and len(prev) and len(ref) * len(prev) < 4e7 and not problems:
+                for ratio in (0.5, 0.8):
+                    want_pairs, _ = O.match(prev, ref, ratio)
+                    got_pairs = c.match(prev, ref, ratio)
+                    if not np.array_equal(want_pairs, got_pairs):
+                        problems.append("matches at ratio %g (%d vs %d)" % (ratio, len(got_pairs), len(want_pairs)))
+                matched[0] += 1
+            prev = ref
             feats_total += len(ref)
         except Exception as e:  # report and go on
             problems = ["exception %r" % (e,)]
@@ -112,7 +124,7 @@ def main():
             print("FAIL case %d %s %dx%d nointerval=%d sigma=%g: %s" % (k, name, w, h, ni, sigma, "; ".join(problems)), flush=True)
         if k % 25 == 24:
             print("... %d cases, %d failures, %d features compared" % (k + 1, bad, feats_total), flush=True)
-    print("fuzz: %d cases, %d failures, %d features compared" % (n, bad, feats_total))
+    print("fuzz: %d cases, %d failures, %d features compared, %d pairs of sets matched" % (n, bad, feats_total, matched[0]))
     return 1 if bad else 0
 
 

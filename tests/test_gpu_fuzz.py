@@ -13,4 +13,4 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_fuzz_parity_short_run():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz_parity.py"), "84", "20261111"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0 and "84 cases, 0 failures" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert r.returncode == 0 and "84 cases, 0 failures" in r.stdout and "pairs of sets matched" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]

@@ -87,9 +87,12 @@ def main():
                     ka = np.lexsort((np.round(ref["ori"], 6), ref["x"], ref["y"], ref["interval"], ref["octave"]))
                     kb = np.lexsort((np.round(got["ori"], 6), got["x"], got["y"], got["interval"], got["octave"]))
                     ra, gb = ref[ka], got[kb]
-                    print("    as sets: integer fields equal %s, descriptors equal %s, scales differing in the last bit: %d"
-                          % (all(np.array_equal(ra[f], gb[f]) for f in ("octave", "interval", "x", "y")),
-                             np.array_equal(ra["descriptor"], gb["descriptor"]), int((ra["scale"] != gb["scale"]).sum())))
+                    def bag(a):
+                        return sorted((int(o), int(i), int(x), int(y), d.astype(np.uint8).tobytes())
+                                      for o, i, x, y, d in zip(a["octave"], a["interval"], a["x"], a["y"], a["descriptor"]))
+                    print("    as sets: integer fields equal %s, (position, descriptor) multisets equal %s, scales differing in "
+                          "the last bit: %d" % (all(np.array_equal(ra[f], gb[f]) for f in ("octave", "interval", "x", "y")),
+                                                bag(ref) == bag(got), int((ra["scale"] != gb["scale"]).sum())))
                     for j in np.nonzero(diff)[0][:8]:
                         print("   ", j, "ref", [ref[f][j] for f in ("octave", "interval", "x", "y")], ref["scale"][j].hex(),
                               ref["ori"][j], "| got", [got[f][j] for f in ("octave", "interval", "x", "y")],

@@ -9,7 +9,7 @@
 #pragma once
 
 #ifndef SG_DD_FN
-#define SG_DD_FN __device__ __forceinline__
+#define SG_DD_FN __host__ __device__ __forceinline__
 #endif
 
 namespace sg {

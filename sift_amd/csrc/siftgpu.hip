@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "sg_internal.h"
+#include "sg_dd.h"
 
 using namespace sg;
 
@@ -2163,8 +2164,9 @@ int sg_calculate_scale(sg_keypoint *kp, size_t n, double sigma, int intervals)
         return SG_E_INVALID;
     for (size_t i = 0; i < n; i++) {
         double intvl = kp[i].interval + kp[i].offset_interval;
-        kp[i].scale = sigma * pow(2.0, kp[i].octave + intvl / intervals);
-        kp[i].octave_scale = sigma * pow(2.0, intvl / intervals);
+        // the routine the device path uses (2^y correctly rounded): the stage chain gives the driver's records exactly
+        kp[i].scale = sigma * sg::sg_exp2_cr(kp[i].octave + intvl / intervals);
+        kp[i].octave_scale = sigma * sg::sg_exp2_cr(intvl / intervals);
     }
     return SG_OK;
 }

@@ -106,10 +106,10 @@ int main(int argc, char **argv)
     CHECK(features.size() == whole.size() && !whole.empty(), "feature count of the stage chain");
     for (size_t i = 0; i < whole.size(); i++) {
         const Keypoint &a = whole[i], &b = features[i];
-        // CalculateScale runs on the host here and on the device inside Sift(): the two pow() routines may
-        // differ in the last bit, which then reaches scale and orientation; everything discrete is identical
+        // CalculateScale runs on the host here and on the device inside Sift(), both through the same correctly
+        // rounded 2^y: equal scales; the orientation sums may differ in their last bits
         bool same = a.x == b.x && a.y == b.y && a.octave == b.octave && a.interval == b.interval && a.dx == b.dx &&
-                    a.dy == b.dy && std::fabs(a.scale - b.scale) <= 1e-13 * a.scale && std::fabs(a.ori - b.ori) <= 1e-9 &&
+                    a.dy == b.dy && a.scale == b.scale && std::fabs(a.ori - b.ori) <= 1e-9 &&
                     a.descr_length == b.descr_length &&
                     std::memcmp(a.descriptor, b.descriptor, sizeof a.descriptor) == 0;
         CHECK(same, "feature records of the stage chain");

@@ -59,6 +59,26 @@ def octave_dims(w, h):
     return out
 
 
+def measured_stream_ceilings():
+    """What plain streams reach on this part (profiles/ubench/stream_ceilings.hip, output committed under
+    profiles/r*/stream_ceilings.txt): read-only, write-only and one-read-one-write rates in GB/s, the yardsticks the
+    pyramid kernels' rates are read against beside the nominal 8 TB/s."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "stream_ceilings.txt")), reverse=True):
+        out = {}
+        try:
+            for line in open(path):
+                m = re.match(r"(linear copy|read only|write only)\s+[\d.]+ ms\s+([\d.]+) TB/s", line)
+                if m:
+                    out[m.group(1).replace(" ", "_")] = float(m.group(2)) * 1e3
+        except OSError:
+            continue
+        if out:
+            out["source"] = os.path.relpath(path, ROOT)
+            return out
+    return None
+
+
 def measured_traffic(kernel, tname, batch, width, height):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/r*/traffic.json, written by
     profiles/summarise.py from separate FETCH_SIZE and WRITE_SIZE runs of this same command); None when no pass
@@ -608,6 +628,7 @@ def main():
             "traffic": measured_traffic(dom, tname, B, W, H),
             "launches": e["launches"], "avg_launch_us": 1e3 * e["ms"] / e["launches"],
             "algorithmic_bytes_per_launch": e["bytes"] / e["launches"],
+            "measured_stream_ceilings_GBps": measured_stream_ceilings(),
             "all_blur_launches_GBps": (tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else None,
             # the same launches priced as in a pyramid that blurs level by level (2 * sizeof(T) per pixel and level):
             # the figure to compare with a run that has no two-level launch

@@ -31,12 +31,30 @@ struct ThreadState {
     int status = SG_OK;
     std::string error;
     bool verbose = false;
+    sg_wire_feature *wire = nullptr; // page-locked landing area of the feature records of a call
+    size_t wire_cap = 0;
     ~ThreadState()
     {
+        if (wire)
+            sg_host_free(wire);
         if (ctx)
             sg_destroy(ctx);
     }
 };
+
+// Wire records into the caller's vector, behind what it holds.  resize() would zero 1120 bytes per new record before
+// they are filled (a Keypoint is a plain struct); instead the records are expanded a few dozen at a time into a buffer
+// that stays in cache and appended from there, so that the vector's memory is written once.
+void append_expanded(std::vector<Keypoint> &features, const sg_wire_feature *w, size_t n)
+{
+    features.reserve(features.size() + n);
+    static thread_local Keypoint block[32];
+    for (size_t i = 0; i < n; i += 32) {
+        const size_t m = n - i < 32 ? n - i : 32;
+        sg_expand_wire(w + i, m, reinterpret_cast<sg_keypoint *>(block));
+        features.insert(features.end(), block, block + m);
+    }
+}
 
 thread_local ThreadState tls;
 
@@ -547,9 +565,12 @@ void run_sift_shared(const Mat &src, std::vector<Keypoint> &features, double sig
         return;
     }
     if (r.n) {
-        const size_t old = features.size();
-        features.resize(old + r.n);
-        sg_expand_wire(r.wire, r.n, reinterpret_cast<sg_keypoint *>(features.data() + old));
+        try {
+            append_expanded(features, r.wire, r.n);
+        } catch (...) { // the caller's vector could not grow: the shared buffer is handed back all the same
+            b->release_wire(r.wire_buf);
+            throw;
+        }
         b->release_wire(r.wire_buf);
     }
     set_status(SG_OK);
@@ -575,12 +596,13 @@ void run_sift(const Mat &src, std::vector<Keypoint> &features, double sigma, int
     sg_ctx *ctx = context_for(src.cols, src.rows, sigma, nointerval);
     if (!ctx)
         return;
-    // Two steps, so that the records are written once, straight behind the features the caller already holds
-    // (the reference appends): the path runs and reports its count, the vector grows, the records come down.
-    size_t n = 0;
+    // The path runs and reports its count; the records come down as 224-byte wire records into a page-locked buffer
+    // of this thread and are expanded behind the features the caller already holds (the reference appends).
+    uint32_t count = 0;
+    const uint8_t *one[1] = {src.data};
     int rc = SG_OK;
     for (int attempt = 0; attempt < 4; attempt++) {
-        rc = sg_extract_begin(ctx, src.data, src.cols, src.rows, src.channels(), src.step, &n);
+        rc = sg_extract_batch_begin(ctx, one, 1, src.cols, src.rows, src.channels(), src.step, 0, &count);
         if (rc != SG_E_CAPACITY || !grow_context(src.cols, src.rows, sigma, nointerval))
             break;
         ctx = tls.ctx;
@@ -588,13 +610,27 @@ void run_sift(const Mat &src, std::vector<Keypoint> &features, double sigma, int
     set_status(rc);
     if (rc != SG_OK)
         return;
-    const size_t old = features.size();
-    features.resize(old + n);
-    rc = sg_extract_fetch(ctx, reinterpret_cast<sg_keypoint *>(features.data() + old), n, &n);
-    set_status(rc);
-    if (rc != SG_OK) {
-        features.resize(old);
-        return;
+    const size_t n = count;
+    if (n > tls.wire_cap) {
+        if (tls.wire)
+            sg_host_free(tls.wire);
+        tls.wire = nullptr;
+        tls.wire_cap = 0;
+        void *q = nullptr;
+        const size_t cap = n + n / 4 + 1024;
+        if (sg_host_alloc(cap * sizeof(sg_wire_feature), &q) != SG_OK) {
+            set_status(SG_E_NOMEM, "no page-locked memory for the feature records");
+            return;
+        }
+        tls.wire = static_cast<sg_wire_feature *>(q);
+        tls.wire_cap = cap;
+    }
+    if (n) {
+        rc = sg_extract_batch_fetch_wire(ctx, tls.wire, tls.wire_cap);
+        set_status(rc);
+        if (rc != SG_OK)
+            return;
+        append_expanded(features, tls.wire, n);
     }
     if (tls.verbose) {
         sg_counters c;

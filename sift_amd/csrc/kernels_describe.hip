@@ -31,17 +31,23 @@ __device__ __forceinline__ void lds_add(double *p, double v)
 }
 
 // Histogram add in 64-bit fixed point.  The LDS pipe of a compute unit takes a 64-lane ds_add_u64 in half the time
-// of a ds_add_f64, and the descriptor kernel is bound by exactly that pipe.  A bin holds an unsigned count of units of
-// 2^-50: a contribution a*b (below 2, already carrying the factor 2^50) is rounded to a whole unit by one fused
-// multiply-add with 2^52 + 2^51, which leaves the integer in the low 51 bits of the result's bit pattern.  Rounding to
-// 2^-50 is finer than the rounding of a double sum of the same size, and integer adds commute, so a bin no longer
-// depends on the order in which its adds arrive.
-constexpr double kFixScale = 1125899906842624.0;     // 2^50
-constexpr double kFixHalfScale = 33554432.0;         // 2^25: the square root of it, carried by each of two factors
-constexpr double kFixMagic = 6755399441055744.0;     // 2^52 + 2^51
+// of a ds_add_f64, and the descriptor kernel is bound by exactly that pipe and by the vector ALU.  A bin holds an
+// unsigned count of units of 2^-50.  The two factors of a contribution carry 2^-512 each on top of that unit, so their
+// product a*b (below 4 in real terms) falls into the subnormal range, where a double's bit pattern IS its value in
+// units of 2^-1074: one multiply rounds the contribution to a whole unit (to nearest, ties to even) and leaves the
+// integer as the result's bit pattern, with nothing to mask off.  (Double-precision subnormals run at full speed and
+// are never flushed on this hardware.)  Rounding to 2^-50 is finer than the rounding of a double sum of the same
+// size, and integer adds commute, so a bin does not depend on the order in which its adds arrive.
+constexpr double kFixScale = 1125899906842624.0; // 2^50: units per 1.0
+// a*b = x * 2^-1024 puts x * 2^50 units into the bit pattern (2^50 * 2^-1074).  The magnitude shares carry 2^-462 (2^-231
+// from each of the two factors of the Gaussian weight), the orientation fractions 2^-562: both stay normal numbers.
+constexpr double kFixWeightHalf = 0x1p-231;
+constexpr double kFixWeight = 0x1p-462;
+constexpr double kFixFrac = 0x1p-562;
+static_assert(kFixWeightHalf * kFixWeightHalf == kFixWeight && kFixWeight * kFixFrac == 0x1p-1024, "the scales meet at 2^-1024");
 __device__ __forceinline__ void lds_add_fixed(unsigned long long *p, double a, double b)
 {
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(__builtin_fma(a, b, kFixMagic)) & 0x0007ffffffffffffull;
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(a * b);
     __hip_atomic_fetch_add(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
@@ -431,14 +437,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
             if (lane + 64 * q < kDescCopies * kDescCopyStride)
                 hist[lane + 64 * q] = 0ull;
         {
-            const double e0 = exp((lane * lane) * wcons) * kFixHalfScale; // both factors of a weight carry 2^25
+            const double e0 = exp((lane * lane) * wcons) * kFixWeightHalf; // both factors of a weight carry 2^-231
             if (lane <= radius && radius + lane < (BIG ? kDescTab : kDescTabSmall)) {
                 etab[radius + lane] = e0;
                 etab[radius - lane] = e0;
             }
             if (BIG && radius >= 64) {
                 const int k2 = lane + 64;
-                const double e1 = exp((k2 * k2) * wcons) * kFixHalfScale;
+                const double e1 = exp((k2 * k2) * wcons) * kFixWeightHalf;
                 if (k2 <= radius && radius + k2 < kDescTab) {
                     etab[radius + k2] = e1;
                     etab[radius - k2] = e1;
@@ -552,7 +558,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                     const double obin = obin_c - __builtin_copysign(q, dy);
                     double weight;
                     if (BIG && !packed)
-                        weight = exp((i * i + jj * jj) * wcons) * kFixScale;
+                        weight = exp((i * i + jj * jj) * wcons) * kFixWeight;
                     else
                         weight = etab[sr] * etab[sc];
                     const double mag = grad_mag * weight;
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                     // the eight bins lie at fixed distances from the (r0, c0) cell in the two orientation columns
                     unsigned long long *hb = h + (r1 * 4 + c1) * 8 - 40;
                     unsigned long long *hb0 = hb + (o0 & 7), *hb1 = hb + ((o0 + 1) & 7);
-                    const double w_o0 = 1.0 - d_o, w_o1 = d_o;
+                    const double w_o1 = d_o * kFixFrac, w_o0 = kFixFrac - w_o1; // (1 - d_o) and d_o, scaled (exactly)
                     // mag split over the two rows, each row over the two columns: the far share is a product, the near
                     // share the remainder
                     const double v_r1 = mag * d_r, v_r0 = mag - v_r1;

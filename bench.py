@@ -226,6 +226,62 @@ def host_api_throughput(W, H, dev_index, cpu_threads):
         return {"error": repr(e)}
 
 
+def packed_rows(buf, n):
+    """n packed 144-byte features as a sorted array of byte strings (a feature set, whatever its order)."""
+    a = buf[: n * 144].cpu().numpy().reshape(n, 144)
+    return np.sort(np.ascontiguousarray(a).view([("b", "V144")]).ravel())
+
+
+def fma_mode_agreement(sift_amd, torch, dev, dev_index, W, H, cap, frames, frame_bytes, first, B, out, counts):
+    """The first frames of the last timed batch again with fused multiply-adds in the Gaussian filters (SG_F64_FMA),
+    compared with what the timed run (the reference's separate multiplies and adds) produced for them: frames whose
+    feature count is the same, features identical byte for byte (position, scale and orientation as packed floats,
+    all 128 descriptor bins), features whose key fields are identical but some bin is not."""
+    n = min(16, B)
+    ctx = sift_amd.SiftGPU(max_width=W, max_height=H, max_batch=n, precision=sift_amd.SG_F64_FMA, device=dev_index)
+    out2 = torch.empty(n * cap * 144, dtype=torch.uint8, device=dev)
+    cnt2 = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx.extract_batch_device(frames.data_ptr() + first * frame_bytes, n, W, H, 3, out2.data_ptr(), cap, cnt2.data_ptr())
+    ctx.sync()
+    c2 = cnt2.cpu().numpy()
+    same_count = n_exact = n_fma = identical = same_keys = 0
+    for i in range(n):
+        a = packed_rows(out[i * cap * 144:], int(counts[i]))
+        b = packed_rows(out2[i * cap * 144:], int(c2[i]))
+        same_count += int(len(a) == len(b))
+        n_exact += len(a)
+        n_fma += len(b)
+        identical += len(np.intersect1d(a, b))
+        ka = np.sort(np.frombuffer(a.tobytes(), np.uint8).reshape(-1, 144)[:, :16].copy().view([("k", "V16")]).ravel())
+        kb = np.sort(np.frombuffer(b.tobytes(), np.uint8).reshape(-1, 144)[:, :16].copy().view([("k", "V16")]).ravel())
+        same_keys += len(np.intersect1d(ka, kb))
+    ctx.close()
+    return {"frames": n, "frames_with_same_count": same_count, "features_exact": n_exact, "features_fma": n_fma,
+            "features_identical_bytes": identical, "features_with_identical_position_scale_orientation": same_keys,
+            "keypoints_identical": same_keys == n_exact == n_fma, "bins_identical": identical == n_exact == n_fma}
+
+
+def fma_mode_throughput(args, B):
+    """The default workload once more, in a run of its own, with SG_F64_FMA: frames per second and the blur kernels'
+    rates when the filters are no longer bound by separate double-precision multiplies and adds."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--batch", str(B), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--width", str(args.width), "--height", str(args.height),
+           "--precision", "f64_fma", "--cap", str(args.cap), "--no-extras", "--no-cpu-baseline"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+        if p.returncode != 0:
+            return {"error": p.stderr.strip()[-300:]}
+        r = json.loads(p.stdout.strip().splitlines()[-1])
+        return {"images_per_s": r["value"], "ms_per_step": r["ms_per_step"],
+                "all_blur_launches_GBps": r["roofline"]["all_blur_launches_GBps"],
+                "all_blur_GBps_level_by_level_bytes": r["roofline"]["all_blur_GBps_level_by_level_bytes"],
+                "blur_kernels_GBps": {k: v["GBps"] for k, v in r["blur_kernels"].items()},
+                "blur_ms_per_step": {k: v for k, v in r["stage_ms_per_step"].items() if k.startswith(("blur", "pyr"))}}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def two_batches_in_flight(args, B):
     """The same workload with two contexts of half the batch each, so that the histogram kernels of one batch
     (vector-ALU work) run beside the pyramid kernels of the other (memory work).  Kernel durations measured that way no
@@ -259,7 +315,10 @@ def main():
                          "context fits when the device has less memory free)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--precision", choices=("f64", "f32"), default="f64")
+    ap.add_argument("--precision", choices=("f64", "f32", "f64_fma"), default="f64",
+                    help="f64: the reference's arithmetic (separate multiplies and adds), bit-identical pyramid;\n"
+                         "f64_fma: double pyramid, fused multiply-adds in the Gaussian filters (tolerance mode);\n"
+                         "f32: float pyramid (tolerance mode)")
     ap.add_argument("--pool", type=int, default=0,
                     help="distinct frames kept resident per GPU (0: 256 on one GPU, 512 per rank on several -- the\n"
                          "256-frame and the 4096-frames-over-8-GPUs configurations)")
@@ -307,8 +366,8 @@ def main():
     W, H, B, K, WU = args.width, args.height, args.batch, args.steps, args.warmup
     if args.pool <= 0:
         args.pool = 256 if world == 1 else 512
-    prec = sift_amd.SG_F64 if args.precision == "f64" else sift_amd.SG_F32
-    esize = 8 if prec == sift_amd.SG_F64 else 4
+    prec = {"f64": sift_amd.SG_F64, "f32": sift_amd.SG_F32, "f64_fma": sift_amd.SG_F64_FMA}[args.precision]
+    esize = 4 if prec == sift_amd.SG_F32 else 8
     nctx = max(1, min(args.contexts, 4))
     def buffers_bytes(b):
         """Device memory this script allocates beside the contexts: the resident frames, the packed-feature buffers
@@ -516,11 +575,19 @@ def main():
         verify, latency = batch_check_and_latency(sift_amd, torch, dev, dev_index, prec, W, H, cap, frames, frame_bytes,
                                                   last_first, B, outs[last_buf[0]], feat_counts)
         host_api = host_api_throughput(W, H, dev_index, args.cpu_threads)
-    overlap = None
+    overlap = f64_fma = None
+    if not args.no_extras and args.precision == "f64" and (W, H) == (1920, 1080):
+        try:
+            f64_fma = fma_mode_agreement(sift_amd, torch, dev, dev_index, W, H, cap, frames, frame_bytes, last_first, B,
+                                         outs[last_buf[0]], feat_counts)
+        except Exception as e:  # a report, never a dependency of the measured path
+            f64_fma = {"error": repr(e)}
     if not args.no_extras and world == 1 and nctx == 1:
         del frames, outs, cnts
         torch.cuda.empty_cache()
         overlap = two_batches_in_flight(args, B)
+        if f64_fma is not None and "error" not in f64_fma:
+            f64_fma.update(fma_mode_throughput(args, B))
 
     images = K * B * world
     value = images / elapsed
@@ -530,6 +597,7 @@ def main():
     taps = [11, 11, 13, 17, 21, 27]
     radius_name = {0: 5, 1: 5, 2: 6, 3: 8, 4: 10, 5: 13}
     tname = "double" if esize == 8 else "float"
+    kflag = ",fma" if args.precision == "f64_fma" else ""
     blur_mode = os.environ.get("SIFTGPU_BLUR", "")
     fused = blur_mode != "2pass"
 
@@ -559,12 +627,17 @@ def main():
                 octs = [d for o, d in enumerate(dims[:tail_first])
                         if min(d) > radius_name[lvl] and not (pair_mask >> o) & 1]
             nbytes = 2.0 * esize * float(sum(r * c for r, c in octs)) * B * K
+            if fused and lvl == 3 and blur_mode in ("", "win"):
+                # the level-3 launch also writes DownSample's output (reference sift.cpp:59-103): level 0 of the next
+                # octave, every pixel once
+                nbytes += esize * float(sum(dims[o + 1][0] * dims[o + 1][1] for o in range(min(tail_first, len(dims) - 1))
+                                            if min(dims[o]) > radius_name[lvl] and dims[o + 1] != dims[o])) * B * K
             ups = fused and lvl == 0 and blur_mode in ("", "win")
             if ups:  # the base blur reads the double gray plane at input resolution instead of an upsampled plane
                 nbytes = (esize * float(dims[0][0] * dims[0][1]) + 8.0 * W * H) * B * K
             if ms > 0:
-                kname = ("%s<%s,R=%d%s>" % (fused_name(ups), tname, radius_name[lvl],
-                                             ",upsampling" if ups else "")) if fused else \
+                kname = ("%s<%s,R=%d%s%s>" % (fused_name(ups), tname, radius_name[lvl],
+                                               ",upsampling" if ups else "", kflag)) if fused else \
                     ("blur_%s_k<%s,R=%d>" % (kind, tname, radius_name[lvl]))
                 blur[key] = {"kernel": kname, "taps": taps[lvl], "launches": int(ln), "avg_us": 1e3 * ms / max(ln, 1),
                              "GBps": nbytes / (ms * 1e-3) / 1e9, "bytes_per_launch_avg": nbytes / max(ln, 1)}
@@ -572,15 +645,18 @@ def main():
                 tot_ms += ms
     # Levels 1 and 2 of an octave from one launch (blur_pair_k): level 0 read once, both levels written once, i.e.
     # 3 * sizeof(T) per pixel of the octave and launch (the two single-level launches it replaces move 4).
-    ms, ln = stage_ms.get("blur_pair", 0.0), stage_launches.get("blur_pair", 0)
-    if ms > 0:
-        nbytes = 3.0 * esize * float(sum(r * c for o, (r, c) in enumerate(dims) if (pair_mask >> o) & 1)) * B * K
-        blur["blur_pair"] = {"kernel": "blur_pair_k<%s,R=5+6>" % tname, "taps": 11, "launches": int(ln),
-                             "avg_us": 1e3 * ms / max(ln, 1), "GBps": nbytes / (ms * 1e-3) / 1e9,
-                             "bytes_per_launch_avg": nbytes / max(ln, 1),
-                             "GBps_as_two_launches": nbytes * (4.0 / 3.0) / (ms * 1e-3) / 1e9}
-        tot_bytes += nbytes
-        tot_ms += ms
+    pair_bytes_saved = 0.0  # what the same levels would move as single-level launches, beyond what the pairs move
+    for key, mask, radii, ntap in (("blur_pair", pair_mask, "5+6", 11),):
+        ms, ln = stage_ms.get(key, 0.0), stage_launches.get(key, 0)
+        if ms > 0:
+            nbytes = 3.0 * esize * float(sum(r * c for o, (r, c) in enumerate(dims) if (mask >> o) & 1)) * B * K
+            blur[key] = {"kernel": "blur_pair_k<%s,R=%s>" % (tname, radii), "taps": ntap, "launches": int(ln),
+                         "avg_us": 1e3 * ms / max(ln, 1), "GBps": nbytes / (ms * 1e-3) / 1e9,
+                         "bytes_per_launch_avg": nbytes / max(ln, 1),
+                         "GBps_as_two_launches": nbytes * (4.0 / 3.0) / (ms * 1e-3) / 1e9}
+            tot_bytes += nbytes
+            tot_ms += ms
+            pair_bytes_saved += nbytes / 3.0
     # The smallest octaves from one launch (pyr_tail_k: one workgroup per frame, planes in LDS): level 0 of its first
     # octave read once, five levels of every octave and level 0 of the later ones written once.
     ms, ln = stage_ms.get("pyr_tail", 0.0), stage_launches.get("pyr_tail", 0)
@@ -604,7 +680,7 @@ def main():
     if det_ms > 0:
         det_bytes = 6.0 * esize * P * B * K  # the six Gaussian levels of every octave, read once
         det_ln = int(stage_launches.get("detect", 0))
-        detect = {"kernel": "detect_k<%s> (fused DoG + 3x3x3 extrema scan; per-octave launches)" % tname,
+        detect = {"kernel": "detect_k<%s> (fused DoG + 3x3x3 extrema scan; one launch over all octaves)" % tname,
                   "launches": det_ln, "GBps": det_bytes / (det_ms * 1e-3) / 1e9,
                   "frac": det_bytes / (det_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}
         by_kernel["detect_k<%s>" % tname] = {"ms": det_ms, "launches": det_ln, "bytes": det_bytes, "taps": 0}
@@ -632,9 +708,8 @@ def main():
             "all_blur_launches_GBps": (tot_bytes / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else None,
             # the same launches priced as in a pyramid that blurs level by level (2 * sizeof(T) per pixel and level):
             # the figure to compare with a run that has no two-level launch
-            "all_blur_GBps_level_by_level_bytes": ((tot_bytes + (blur["blur_pair"]["bytes_per_launch_avg"] *
-                                                    blur["blur_pair"]["launches"] / 3.0 if "blur_pair" in blur else 0.0))
-                                                   / (tot_ms * 1e-3) / 1e9) if tot_ms > 0 else None,
+            "all_blur_GBps_level_by_level_bytes": ((tot_bytes + pair_bytes_saved) / (tot_ms * 1e-3) / 1e9)
+            if tot_ms > 0 else None,
         }
 
     cpu_baseline = None
@@ -657,9 +732,9 @@ def main():
         "value": value, "unit": "images/s", "n_gpus": world, "steps": K, "warmup": WU,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64" if esize == 8 else "f32", "data": "synthetic",
-        "config": {"workload": "%d frames %dx%d per GPU (%d steps x %d frames, vnoise5 seeds %d..), sigma 1.6, "
-                               "3 intervals, double-size base, packed 144-B features%s"
-                               % (K * B, W, H, K, B, seed0,
+        "config": {"workload": "%d frames %dx%d per GPU (%d steps x %d frames; %d distinct frames, vnoise5 seeds "
+                               "%d.., taken in turn), sigma 1.6, 3 intervals, double-size base, packed 144-B features%s"
+                               % (K * B, W, H, K, B, pool, seed0,
                                   (", %d distinct frames per rank (global frame f: seed 1000 + f, rank f // %d), "
                                    "all-gather-v of the feature sets after every step" % (pool, pool)) if world > 1 else ""),
                    "batch": B, "contexts_in_flight": nctx, "precision": args.precision,
@@ -670,7 +745,7 @@ def main():
             valu_roofline("descr_k<double,false>", work[0], stage_ms.get("descr", 0.0) / K) if esize == 8 else None,
             valu_roofline("orient_k<double,false>", work[1], stage_ms.get("orient", 0.0) / K) if esize == 8 else None) if r],
         "batch_check": verify, "latency_ms": latency, "host_api": host_api,
-        "two_batches_in_flight": overlap, "exchange": exchange,
+        "two_batches_in_flight": overlap, "f64_fma": f64_fma, "exchange": exchange,
         "features_last_step": int(feat_counts.astype(np.int64).sum()), "features_gathered_last_step": gathered_last,
         "stage_ms_per_step": {k: v / K for k, v in stage_ms.items() if v > 0},
         "blur_kernels": blur, "detect_kernel": detect,

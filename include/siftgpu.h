@@ -38,7 +38,10 @@ typedef enum sg_status {
 
 typedef enum sg_precision {
     SG_F64 = 0, /* pyramid stored and filtered in double, like the reference's pixel_t (sift.h:16) */
-    SG_F32 = 1  /* pyramid stored in float; keypoint arithmetic stays in double */
+    SG_F32 = 1, /* pyramid stored in float; keypoint arithmetic stays in double */
+    SG_F64_FMA = 2 /* SG_F64 with fused multiply-adds in the Gaussian filters: one rounding per tap instead of the
+                      reference's two, so pyramid values differ from a scalar evaluation of sift.cpp:323-326 in their
+                      last bits (relative 1e-16); a tolerance mode like SG_F32, four times faster in the widest filters */
 } sg_precision;
 
 /* Same layout as the reference's struct Keypoint (sift/sift.h:75-102): 1120 bytes. */

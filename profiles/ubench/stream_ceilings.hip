@@ -80,8 +80,10 @@ int main(int argc, char **argv)
     timeit("linear copy x32 blocks", 2.0 * n * 8, [&] { linear_k<<<256 * 32, 256>>>((const double2 *)a, (double2 *)b, n / 2); });
     timeit("read only", 1.0 * n * 8, [&] { read_k<<<256 * 16, 256>>>((const double2 *)a, b, n / 2); });
     timeit("write only", 1.0 * n * 8, [&] { write_k<<<256 * 16, 256>>>((double2 *)b, n / 2); });
-    int segs[] = {540, 270, 136, 68};
-    for (int seg : segs) {
+    int segs[16] = {540, 270, 136, 68}, nsegs = 4;
+    if (argc > 2) { nsegs = 0; for (int i = 2; i < argc && nsegs < 16; i++) segs[nsegs++] = atoi(argv[i]); }
+    for (int si = 0; si < nsegs; si++) {
+        const int seg = segs[si];
         int nseg = (rows + seg - 1) / seg;
         char nm[80];
 #define RUN(NW, V, PF, NT, REMAP) { const int nsx = (cols / (64 * V) + NW - 1) / NW; int tot = nsx * nseg * B; if (REMAP) tot = (tot + 7) / 8 * 8; \
@@ -95,6 +97,11 @@ int main(int argc, char **argv)
         RUN(4, 4, 4, false, 0)
         RUN(2, 4, 4, false, 0)
         RUN(1, 2, 4, false, 0)
+        RUN(16, 2, 4, false, 0)
+        RUN(16, 2, 4, false, 1)
+        RUN(4, 2, 1, false, 0)
+        RUN(4, 2, 2, false, 0)
+        RUN(4, 2, 2, false, 1)
     }
     return 0;
 }

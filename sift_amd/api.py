@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SIFTGPU_LIB") or os.path.join(_HERE, "libsiftgpu.so")
 
 SG_OK, SG_E_INVALID, SG_E_HIP, SG_E_CAPACITY, SG_E_UNSUPPORTED, SG_E_NOMEM = 0, -1, -2, -3, -4, -5
-SG_F64, SG_F32 = 0, 1
+SG_F64, SG_F32, SG_F64_FMA = 0, 1, 2
 STAGES = (("prep",) + tuple("blur_row%d" % i for i in range(6)) + tuple("blur_col%d" % i for i in range(6)) +
           ("downsample", "detect", "compact", "refine", "orient", "descr", "sort", "blur_pair", "pyr_tail"))
 

@@ -42,10 +42,58 @@ __device__ __forceinline__ int reflect101_once(int p, int len)
 }
 
 // acc + k*x.  The double pyramid keeps the reference's separate multiply and add (the library is built without
-// contraction, and results are bit-identical to a scalar evaluation); the float pyramid is a tolerance mode and
-// takes the fused form, which halves the arithmetic of the wide filters.
-__device__ __forceinline__ double blur_madd(double acc, double k, double x) { return acc + k * x; }
+// contraction, and results are bit-identical to a scalar evaluation) unless F selects the fused form, which halves
+// the arithmetic of the wide filters and rounds once per tap instead of twice (SG_F64_FMA: a tolerance mode, the
+// pyramid then differs from the scalar evaluation in its last bits).  The float pyramid is a tolerance mode anyway
+// and always takes the fused form.
+template <bool F>
+__device__ __forceinline__ double blur_madd(double acc, double k, double x)
+{
+    if constexpr (F)
+        return __builtin_fma(k, x, acc);
+    else
+        return acc + k * x;
+}
+template <bool F>
 __device__ __forceinline__ float blur_madd(float acc, float k, float x) { return __builtin_fmaf(k, x, acc); }
+
+// Tile (strip group, row segment, frame) of a workgroup of the strip-walking kernels.  Plain form: a 3-D launch.
+// XCD-aware form (a 1-D launch of 8 * ceil(tiles / 8) workgroups): workgroups are dealt round-robin over the eight
+// XCDs, so workgroup i runs on XCD i mod 8; tile numbers are handed out such that each XCD walks a contiguous run of
+// the tile list (strip groups fastest, then segments, then frames): neighbouring strips, whose halo columns overlap,
+// and the segments of one frame then meet in one L2, and each XCD's address translation covers an eighth of the planes.
+// (Placement is an assumption about speed only; every tile is taken exactly once wherever its workgroup runs.)
+struct TileGrid {
+    int nx, ny, nz;
+    int remap; // 1: XCD-aware 1-D launch
+};
+
+__device__ __forceinline__ bool tile_of_block(const TileGrid &g, int &bx, int &by, int &bz)
+{
+    if (!g.remap) {
+        bx = blockIdx.x;
+        by = blockIdx.y;
+        bz = blockIdx.z;
+        return true;
+    }
+    const unsigned int total = (unsigned int)g.nx * g.ny * g.nz, per = (total + 7) / 8;
+    const unsigned int t = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    if ((blockIdx.x >> 3) >= per || t >= total)
+        return false;
+    bx = (int)(t % (unsigned int)g.nx);
+    const unsigned int r = t / (unsigned int)g.nx;
+    by = (int)(r % (unsigned int)g.ny);
+    bz = (int)(r / (unsigned int)g.ny);
+    return true;
+}
+
+static dim3 tile_launch_grid(const TileGrid &g)
+{
+    if (!g.remap)
+        return dim3(g.nx, g.ny, g.nz);
+    const unsigned int total = (unsigned int)g.nx * g.ny * g.nz;
+    return dim3((total + 7) / 8 * 8);
+}
 
 template <typename T, int V>
 struct VecOf;
@@ -57,7 +105,7 @@ struct VecOf<float, 4> { typedef float4 type; };
 // ---- row pass -------------------------------------------------------------------------------------
 // Block = 4 waves, one row segment of TW = 64*V*U pixels per wave: each lane produces U groups of V
 // adjacent outputs from a (TW + 2R)-pixel LDS image of the row segment.
-template <typename T, int R, int V, int U>
+template <typename T, int R, int V, int U, bool F = false>
 __global__ __launch_bounds__(256) void blur_row_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols,
                                                   int spitch, int dpitch, size_t simg, size_t dimg, Taps<T> taps)
 {
@@ -111,7 +159,7 @@ __global__ __launch_bounds__(256) void blur_row_k(const T *__restrict__ src, T *
             acc[v] = taps.k[0] * w[v];
 #pragma unroll
             for (int t = 1; t <= 2 * R; t++)
-                acc[v] = blur_madd(acc[v], taps.k[t], w[v + t]);
+                acc[v] = blur_madd<F>(acc[v], taps.k[t], w[v + t]);
         }
         if (xb + V <= cols) {
             vec_t o;
@@ -133,7 +181,7 @@ __global__ __launch_bounds__(256) void blur_row_k(const T *__restrict__ src, T *
 // Block = 4 waves over a tile of TW = 64*V columns x TH = 4*RPT rows.  The (TH + 2R) x TW input tile
 // is staged in LDS (rows outside the plane by reflection); every thread then produces RPT vertically
 // adjacent outputs for its V columns from a register window of RPT + 2R rows.
-template <typename T, int R, int V, int RPT>
+template <typename T, int R, int V, int RPT, bool F = false>
 __global__ __launch_bounds__(256) void blur_col_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols,
                                                   int spitch, int dpitch, size_t simg, size_t dimg, Taps<T> taps)
 {
@@ -189,7 +237,7 @@ __global__ __launch_bounds__(256) void blur_col_k(const T *__restrict__ src, T *
             T acc = taps.k[R] * win[r + R][c];
 #pragma unroll
             for (int t = 1; t <= R; t++)
-                acc = blur_madd(acc, taps.k[R + t], win[r + R + t][c] + win[r + R - t][c]);
+                acc = blur_madd<F>(acc, taps.k[R + t], win[r + R + t][c] + win[r + R - t][c]);
             po[c] = acc;
         }
         T *dr = d + (size_t)y * dpitch;
@@ -306,7 +354,7 @@ __global__ __launch_bounds__(256) void blur_fused_k(const T *__restrict__ src, T
                             if (tt == 0)
                                 po[vo] = taps.k[0] * pv[j];
                             else if (tt > 0 && tt <= 2 * R)
-                                po[vo] = blur_madd(po[vo], taps.k[tt], pv[j]);
+                                po[vo] = blur_madd<false>(po[vo], taps.k[tt], pv[j]);
                         }
                     }
                     (void)prev;
@@ -347,7 +395,7 @@ __global__ __launch_bounds__(256) void blur_fused_k(const T *__restrict__ src, T
                     T *pa = reinterpret_cast<T *>(&acc[j]);
 #pragma unroll
                     for (int e = 0; e < V; e++)
-                        pa[e] = blur_madd(pa[e], taps.k[R + tt], pu[e] + pd[e]);
+                        pa[e] = blur_madd<false>(pa[e], taps.k[R + tt], pu[e] + pd[e]);
                 }
                 if (tt < R) {
                     // slide: up[j] <- ring[R + j + tt + 1], dn[j] <- ring[R + j - tt - 1]
@@ -440,12 +488,15 @@ struct WinGray {
     static_assert((DI - 1) * PER < 64, "outstanding loads fit the counter");
 };
 
-template <typename T, int R, int V, bool UPS = false, bool GDMA = false>
+template <typename T, int R, int V, bool UPS = false, bool GDMA = false, bool F = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(win_waves_per_simd(R), win_waves_per_simd(R))))
 void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols, int spitch, int dpitch, size_t simg,
                 size_t dimg, int seg, Taps<T> taps, T *__restrict__ dec, int dec_rows, int dec_cols, int dec_pitch,
-                size_t dec_img)
+                size_t dec_img, TileGrid tg)
 {
+    int bx, by, bz;
+    if (!tile_of_block(tg, bx, by, bz))
+        return; // the whole workgroup; there is no barrier in this kernel
     typedef typename VecOf<T, V>::type vec_t;
     constexpr int TW = 64 * V;
     constexpr int KR = win_rows_per_iter(R);           // input rows per iteration
@@ -459,14 +510,14 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
     T *raw = reinterpret_cast<T *>(smem_raw) + (size_t)wave * KR * RAWW;
     // the four waves of a workgroup take four neighbouring strips of the same rows, so that the halo columns one
     // wave reads are the columns its neighbour streams at about the same time
-    const int x0 = (blockIdx.x * 4 + wave) * TW;
-    const int ys = blockIdx.y * seg;
+    const int x0 = (bx * 4 + wave) * TW;
+    const int ys = by * seg;
     if (x0 >= cols)
         return; // the whole wave; there is no barrier in this kernel
     const int ye = min(ys + seg, rows);
     const int xb = x0 + lane * V;
-    const T *s = src + blockIdx.z * simg;
-    T *d = dst + blockIdx.z * dimg;
+    const T *s = src + bz * simg;
+    T *d = dst + bz * dimg;
     const int n_iter = (ye - ys + 2 * R + KR - 1) / KR;
     const bool strip_full = x0 + TW <= cols; // wave-uniform: every lane's vector lies inside the row
     const int hx = lane < R ? x0 - R + lane : x0 + TW + (lane - R); // halo column of this lane (lanes < 2R)
@@ -487,7 +538,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
     // instead of being read.  Output (Y, X) with Y' = min(Y, rows-3), X' = min(X, cols-3) (the last two rows and
     // columns repeat row rows-3 and column cols-3), i = Y'/2, j = X'/2:  s(i,j) | (s(i,j)+s(i,j+1))/2 |
     // (s(i,j)+s(i+1,j))/2 | (s(i+1,j)+s(i,j)+s(i+1,j+1)+s(i,j+1))/4  by the parities of Y' and X'.
-    const double *gsrc = reinterpret_cast<const double *>(src) + blockIdx.z * simg;
+    const double *gsrc = reinterpret_cast<const double *>(src) + bz * simg;
     // GDMA: the gray rows an iteration needs (two per output row: i = Y'/2 and i + 1) are staged into a wave-private
     // LDS ring by direct-to-LDS loads, DI iterations ahead, and the upsampled pixels are formed from there; a gray row
     // image starts FRONT columns left of the strip's first gray column (an even column: 16-byte pieces are aligned).
@@ -664,7 +715,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                         if (tt == 0)
                             po[vo] = taps.k[0] * pv[j];
                         else if (tt > 0 && tt <= 2 * R)
-                            po[vo] = blur_madd(po[vo], taps.k[tt], pv[j]);
+                            po[vo] = blur_madd<F>(po[vo], taps.k[tt], pv[j]);
                     }
                 }
             }
@@ -690,7 +741,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                     const T *pd = reinterpret_cast<const T *>(&win[R + k - tt]);
 #pragma unroll
                     for (int e = 0; e < V; e++)
-                        pa[e] = blur_madd(pa[e], taps.k[R + tt], pu[e] + pd[e]);
+                        pa[e] = blur_madd<F>(pa[e], taps.k[R + tt], pu[e] + pd[e]);
                 }
                 const int y = ys + n0 + k;
                 if (y < ye) {
@@ -706,7 +757,7 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                     // DownSample (reference sift/sift.cpp:59-103) of the level just written: dec(m, n) = dst(2m, 2n).
                     // ys and n0 are even, so the even rows are the even k.
                     if ((k & 1) == 0 && dec != nullptr && (y >> 1) < dec_rows) {
-                        T *dd = dec + blockIdx.z * dec_img + (size_t)(y >> 1) * dec_pitch;
+                        T *dd = dec + bz * dec_img + (size_t)(y >> 1) * dec_pitch;
 #pragma unroll
                         for (int e = 0; e < V; e += 2)
                             if (((xb + e) >> 1) < dec_cols)
@@ -777,26 +828,29 @@ struct WinDma {
     static_assert((DI - 1) * 2 * KR < 64, "outstanding loads fit the counter");
 };
 
-template <typename T, int R, int V>
+template <typename T, int R, int V, bool F = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(dma_waves_per_simd(R), dma_waves_per_simd(R))))
 void blur_dma_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int cols, int spitch, int dpitch, size_t simg,
                 size_t dimg, int seg, Taps<T> taps, T *__restrict__ dec, int dec_rows, int dec_cols, int dec_pitch,
-                size_t dec_img)
+                size_t dec_img, TileGrid tg)
 {
+    int bx, by, bz;
+    if (!tile_of_block(tg, bx, by, bz))
+        return; // the whole workgroup, before it has requested anything; there is no barrier in this kernel
     typedef typename VecOf<T, V>::type vec_t;
     using G = WinDma<T, R, V>;
     constexpr int TW = G::TW, KR = G::KR, WIN = 2 * R + KR, A = G::A, NWIN = G::NWIN, DI = G::DI;
     constexpr int ROWE = G::ROWB / (int)sizeof(T); // elements per row image
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int x0 = (blockIdx.x * 4 + wave) * TW;
-    const int ys = blockIdx.y * seg;
+    const int x0 = (bx * 4 + wave) * TW;
+    const int ys = by * seg;
     if (x0 >= cols)
         return; // the whole wave, before it has requested anything; there is no barrier in this kernel
     const int ye = min(ys + seg, rows);
     const int xb = x0 + lane * V;
-    const T *s = src + blockIdx.z * simg;
-    T *d = dst + blockIdx.z * dimg;
+    const T *s = src + bz * simg;
+    T *d = dst + bz * dimg;
     const int n_iter = (ye - ys + 2 * R + KR - 1) / KR;
     const bool strip_full = x0 + TW <= cols; // wave-uniform: every lane's vector lies inside the row
     const int cbase = x0 - R - A;            // column of element 0 of a row image
@@ -899,7 +953,7 @@ void blur_dma_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                             if (tt == 0)
                                 po[vo] = taps.k[0] * pv[j];
                             else if (tt > 0 && tt <= 2 * R)
-                                po[vo] = blur_madd(po[vo], taps.k[tt], pv[j]);
+                                po[vo] = blur_madd<F>(po[vo], taps.k[tt], pv[j]);
                         }
                     }
                 }
@@ -934,7 +988,7 @@ void blur_dma_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                     const T *pd = reinterpret_cast<const T *>(&win[R + k - tt]);
 #pragma unroll
                     for (int e = 0; e < V; e++)
-                        pa[e] = blur_madd(pa[e], taps.k[R + tt], pu[e] + pd[e]);
+                        pa[e] = blur_madd<F>(pa[e], taps.k[R + tt], pu[e] + pd[e]);
                 }
                 const int y = ys + n0 + k;
                 if (y < ye) {
@@ -949,7 +1003,7 @@ void blur_dma_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                     }
                     // DownSample (reference sift/sift.cpp:59-103) of the level just written: dec(m, n) = dst(2m, 2n)
                     if ((k & 1) == 0 && dec != nullptr && (y >> 1) < dec_rows) {
-                        T *dd = dec + blockIdx.z * dec_img + (size_t)(y >> 1) * dec_pitch;
+                        T *dd = dec + bz * dec_img + (size_t)(y >> 1) * dec_pitch;
 #pragma unroll
                         for (int e = 0; e < V; e += 2)
                             if (((xb + e) >> 1) < dec_cols)
@@ -1003,11 +1057,15 @@ struct PairGeom {
 #ifndef SG_PAIR_WPE
 #define SG_PAIR_WPE 3
 #endif
-template <typename T, int RA, int RB, int V>
+template <typename T, int RA, int RB, int V, bool F = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SG_PAIR_WPE, SG_PAIR_WPE)))
 void blur_pair_k(const T *__restrict__ src, T *__restrict__ dst_a, T *__restrict__ dst_b, int rows, int cols, int spitch,
-                 int apitch, int bpitch, size_t simg, size_t aimg, size_t bimg, int seg, Taps<T> taps_a, Taps<T> taps_b)
+                 int apitch, int bpitch, size_t simg, size_t aimg, size_t bimg, int seg, Taps<T> taps_a, Taps<T> taps_b,
+                 TileGrid tg)
 {
+    int bx, by, bz;
+    if (!tile_of_block(tg, bx, by, bz))
+        return; // the whole workgroup, before it has requested anything; there is no barrier in this kernel
     typedef typename VecOf<T, V>::type vec_t;
     typedef T lds_vec_t __attribute__((ext_vector_type(V)));
     typedef const volatile __attribute__((address_space(3))) lds_vec_t *lds_vec_ptr;
@@ -1019,19 +1077,19 @@ void blur_pair_k(const T *__restrict__ src, T *__restrict__ dst_a, T *__restrict
     constexpr int WINA = 2 * RA + KR, WINB = 2 * RB + KR;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int strip = blockIdx.x * 4 + wave;
+    const int strip = bx * 4 + wave;
     const int own0 = strip * PITCH; // first column this wave stores
     if (own0 >= cols)
         return; // the whole wave, before it has requested anything; there is no barrier in this kernel
     const int own1 = min(own0 + PITCH, cols);
     const int X0 = own0 - P::MG; // first column the stages compute (negative in the first strip)
-    const int ys = blockIdx.y * seg;
+    const int ys = by * seg;
     const int ye = min(ys + seg, rows);
     const int xb = X0 + lane * V; // this lane's columns xb .. xb+V-1
     const bool lane_owns = xb >= own0 && xb < own1;
     const bool lane_full = lane_owns && xb + V <= own1;
-    const T *s = src + blockIdx.z * simg;
-    T *da = dst_a + blockIdx.z * aimg, *db = dst_b + blockIdx.z * bimg;
+    const T *s = src + bz * simg;
+    T *da = dst_a + bz * aimg, *db = dst_b + bz * bimg;
     const int n_iter = (ye - ys + 2 * LEAD + KR - 1) / KR;
     // stage A: raw input rows in a ring filled by direct-to-LDS loads; element 0 of a row image is column cbase
     const int cbase = X0 - RA - AA;
@@ -1075,7 +1133,7 @@ void blur_pair_k(const T *__restrict__ src, T *__restrict__ dst_a, T *__restrict
                     if (tt == 0)
                         po[vo] = taps.k[0] * rv[q][j];
                     else if (tt > 0 && tt <= 2 * R)
-                        po[vo] = blur_madd(po[vo], taps.k[tt], rv[q][j]);
+                        po[vo] = blur_madd<F>(po[vo], taps.k[tt], rv[q][j]);
                 }
             }
         }
@@ -1096,7 +1154,7 @@ void blur_pair_k(const T *__restrict__ src, T *__restrict__ dst_a, T *__restrict
             const T *pd = reinterpret_cast<const T *>(&win[R + k - tt]);
 #pragma unroll
             for (int e = 0; e < V; e++)
-                pa[e] = blur_madd(pa[e], taps.k[R + tt], pu[e] + pd[e]);
+                pa[e] = blur_madd<F>(pa[e], taps.k[R + tt], pu[e] + pd[e]);
         }
         return acc;
     };
@@ -1224,7 +1282,7 @@ static bool blur_dma_ok(const Plane &src)
 }
 
 // ---- any-radius fallback (one thread per output pixel, taps in global memory) ------------------------
-template <typename T>
+template <typename T, bool F = false>
 __global__ __launch_bounds__(256) void blur_row_any_k(const T *src, T *dst, int rows, int cols, int spitch,
                                                       int dpitch, size_t simg, size_t dimg, const T *taps, int n)
 {
@@ -1236,11 +1294,11 @@ __global__ __launch_bounds__(256) void blur_row_any_k(const T *src, T *dst, int 
     int h = n / 2;
     T acc = taps[0] * s[reflect101(x - h, cols)];
     for (int t = 1; t < n; t++)
-        acc = blur_madd(acc, taps[t], s[reflect101(x - h + t, cols)]);
+        acc = blur_madd<F>(acc, taps[t], s[reflect101(x - h + t, cols)]);
     dst[blockIdx.z * dimg + (size_t)y * dpitch + x] = acc;
 }
 
-template <typename T>
+template <typename T, bool F = false>
 __global__ __launch_bounds__(256) void blur_col_any_k(const T *src, T *dst, int rows, int cols, int spitch,
                                                       int dpitch, size_t simg, size_t dimg, const T *taps, int n)
 {
@@ -1252,7 +1310,7 @@ __global__ __launch_bounds__(256) void blur_col_any_k(const T *src, T *dst, int 
     int h = n / 2;
     T acc = taps[h] * s[(size_t)y * spitch];
     for (int t = 1; t <= h; t++)
-        acc = blur_madd(acc, taps[h + t], s[(size_t)reflect101(y + t, rows) * spitch] + s[(size_t)reflect101(y - t, rows) * spitch]);
+        acc = blur_madd<F>(acc, taps[h + t], s[(size_t)reflect101(y + t, rows) * spitch] + s[(size_t)reflect101(y - t, rows) * spitch]);
     dst[blockIdx.z * dimg + (size_t)y * dpitch + x] = acc;
 }
 
@@ -1303,7 +1361,7 @@ __device__ __forceinline__ void tail_fill_halo(T *A, int rows, int cols, int tid
 // ones in the column pass: the pair shares all but one of its window's LDS reads, and LDS bandwidth is what bounds a
 // workgroup that filters out of LDS.  Taps live in scalar registers.  Column windows that cross the top or bottom
 // take reflected row indices (one reflection suffices while rows > R + 1, the general loop otherwise).
-template <typename T, int R>
+template <typename T, int R, bool F>
 __device__ __forceinline__ void tail_level(T *A, T *Bp, T *out, int rows, int cols, int pitch, const T *kp, int tid)
 {
     T k[2 * R + 1];
@@ -1322,8 +1380,8 @@ __device__ __forceinline__ void tail_level(T *A, T *Bp, T *out, int rows, int co
         T acc0 = k[0] * w[0], acc1 = k[0] * w[1];
 #pragma unroll
         for (int t = 1; t <= 2 * R; t++) {
-            acc0 = blur_madd(acc0, k[t], w[t]);
-            acc1 = blur_madd(acc1, k[t], w[t + 1]);
+            acc0 = blur_madd<F>(acc0, k[t], w[t]);
+            acc1 = blur_madd<F>(acc1, k[t], w[t + 1]);
         }
         Bp[y * cols + x] = acc0;
         if (x + 1 < cols)
@@ -1349,18 +1407,18 @@ __device__ __forceinline__ void tail_level(T *A, T *Bp, T *out, int rows, int co
             acc1 = k[R] * w[R + 1];
 #pragma unroll
             for (int t = 1; t <= R; t++) {
-                acc0 = blur_madd(acc0, k[R + t], w[R + t] + w[R - t]);
-                acc1 = blur_madd(acc1, k[R + t], w[R + 1 + t] + w[R + 1 - t]);
+                acc0 = blur_madd<F>(acc0, k[R + t], w[R + t] + w[R - t]);
+                acc1 = blur_madd<F>(acc1, k[R + t], w[R + 1 + t] + w[R + 1 - t]);
             }
         } else {
             acc0 = kp[R] * Bp[y * cols + x];
             for (int t = 1; t <= R; t++)
-                acc0 = blur_madd(acc0, kp[R + t],
+                acc0 = blur_madd<F>(acc0, kp[R + t],
                                  Bp[reflect101(y + t, rows) * cols + x] + Bp[reflect101(y - t, rows) * cols + x]);
             if (two) {
                 acc1 = kp[R] * Bp[(y + 1) * cols + x];
                 for (int t = 1; t <= R; t++)
-                    acc1 = blur_madd(acc1, kp[R + t], Bp[reflect101(y + 1 + t, rows) * cols + x] +
+                    acc1 = blur_madd<F>(acc1, kp[R + t], Bp[reflect101(y + 1 + t, rows) * cols + x] +
                                                           Bp[reflect101(y + 1 - t, rows) * cols + x]);
             }
         }
@@ -1376,7 +1434,7 @@ __device__ __forceinline__ void tail_level(T *A, T *Bp, T *out, int rows, int co
     __syncthreads();
 }
 
-template <typename T>
+template <typename T, bool F = false>
 __global__ __launch_bounds__(kTailThreads) void pyr_tail_k(OctaveTab tab, int first, TailTaps<T> taps,
                                                            unsigned int a_elems)
 {
@@ -1399,11 +1457,11 @@ __global__ __launch_bounds__(kTailThreads) void pyr_tail_k(OctaveTab tab, int fi
             T *out = (T *)tab.lv[o][l] + (size_t)b * tab.img_stride[o];
             const T *kp = taps.k[l - 1];
             switch (taps.R[l - 1]) {
-            case 5: tail_level<T, 5>(A, Bp, out, rows, cols, pitch, kp, tid); break;
-            case 6: tail_level<T, 6>(A, Bp, out, rows, cols, pitch, kp, tid); break;
-            case 8: tail_level<T, 8>(A, Bp, out, rows, cols, pitch, kp, tid); break;
-            case 10: tail_level<T, 10>(A, Bp, out, rows, cols, pitch, kp, tid); break;
-            default: tail_level<T, 13>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            case 5: tail_level<T, 5, F>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            case 6: tail_level<T, 6, F>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            case 8: tail_level<T, 8, F>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            case 10: tail_level<T, 10, F>(A, Bp, out, rows, cols, pitch, kp, tid); break;
+            default: tail_level<T, 13, F>(A, Bp, out, rows, cols, pitch, kp, tid); break;
             }
             if (l == 3 && o + 1 < tab.octaves) { // DownSample: every second pixel of every second row
                 const int r2 = tab.rows[o + 1], c2 = tab.cols[o + 1], p2 = tab.pitch[o + 1];
@@ -1448,7 +1506,7 @@ int pyr_tail_first(const OctaveTab &tab, const int *ntaps, int prec)
         const bool halves = tab.rows[o] == tab.rows[o - 1] / 2 && tab.cols[o] == tab.cols[o - 1] / 2;
         if (tab.rows[o] < 2 || tab.cols[o] < 2 || !halves)
             break;
-        const size_t bytes = prec == SG_F64 ? tail_lds_bytes<double>(tab, o) : tail_lds_bytes<float>(tab, o);
+        const size_t bytes = prec_store(prec) == SG_F64 ? tail_lds_bytes<double>(tab, o) : tail_lds_bytes<float>(tab, o);
         if (bytes > kTailLdsBytes)
             break;
         first = o;
@@ -1456,7 +1514,7 @@ int pyr_tail_first(const OctaveTab &tab, const int *ntaps, int prec)
     return first;
 }
 
-template <typename T>
+template <typename T, bool F>
 static bool tail_dispatch(const OctaveTab &tab, int first, int B, const double *const *taps, const int *ntaps,
                           hipStream_t s)
 {
@@ -1469,7 +1527,7 @@ static bool tail_dispatch(const OctaveTab &tab, int first, int B, const double *
     {
         std::lock_guard<std::mutex> lk(allowed_mutex);
         if (allowed[dev] == 0) {
-            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&pyr_tail_k<T>),
+            const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(&pyr_tail_k<T, F>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize,
                                                 (int)kTailLdsBytes) == hipSuccess;
             if (!ok)
@@ -1489,7 +1547,7 @@ static bool tail_dispatch(const OctaveTab &tab, int first, int B, const double *
         for (int i = 0; i < kMaxTaps; i++)
             tt.k[l][i] = padded.k[i];
     }
-    pyr_tail_k<T><<<dim3(B), kTailThreads, tail_lds_bytes<T>(tab, first), s>>>(tab, first, tt,
+    pyr_tail_k<T, F><<<dim3(B), kTailThreads, tail_lds_bytes<T>(tab, first), s>>>(tab, first, tt,
                                                                               (unsigned int)tail_a_elems<T>(tab, first));
     return true;
 }
@@ -1499,8 +1557,10 @@ bool launch_pyr_tail(const OctaveTab &tab, int first, int B, const double *const
 {
     if (first < 1 || first >= tab.octaves || B < 1)
         return false;
-    return prec == SG_F64 ? tail_dispatch<double>(tab, first, B, taps, ntaps, s)
-                          : tail_dispatch<float>(tab, first, B, taps, ntaps, s);
+    if (prec_store(prec) != SG_F64)
+        return tail_dispatch<float, false>(tab, first, B, taps, ntaps, s);
+    return prec_fma(prec) ? tail_dispatch<double, true>(tab, first, B, taps, ntaps, s)
+                          : tail_dispatch<double, false>(tab, first, B, taps, ntaps, s);
 }
 
 // ---- dispatch ---------------------------------------------------------------------------------------
@@ -1543,7 +1603,7 @@ static T *upload_taps(const double *taps, int n, hipStream_t s)
     return d;
 }
 
-template <typename T, int V, int U>
+template <typename T, int V, int U, bool F>
 static bool row_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s,
                          const void *d_taps)
 {
@@ -1559,7 +1619,7 @@ static bool row_dispatch(const Plane &src, const Plane &dst, int B, const double
     dim3 g((cols + TW - 1) / TW, (rows + 3) / 4, B);
 #define SG_ROW_CASE(RR)                                                                                               \
     case RR:                                                                                                          \
-        blur_row_k<T, RR, V, U><<<g, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,     \
+        blur_row_k<T, RR, V, U, F><<<g, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,     \
                                                   src.img_stride, dst.img_stride, padded_taps<T>(taps, n, RR));       \
         break;
     switch (R) {
@@ -1570,13 +1630,13 @@ static bool row_dispatch(const Plane &src, const Plane &dst, int B, const double
         SG_ROW_CASE(13)
     default: {
         if (d_taps) {
-            blur_row_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
+            blur_row_any_k<T, F><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
                                                  src.img_stride, dst.img_stride, (const T *)d_taps, n);
         } else {
             T *dt = upload_taps<T>(taps, n, s);
             if (!dt)
                 return false; // no device memory for the taps (or more taps than the any-radius kernels take)
-            blur_row_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
+            blur_row_any_k<T, F><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
                                                  src.img_stride, dst.img_stride, dt, n);
             hipStreamSynchronize(s);
             hipFree(dt);
@@ -1587,7 +1647,7 @@ static bool row_dispatch(const Plane &src, const Plane &dst, int B, const double
     return true;
 }
 
-template <typename T, int V, int RPT>
+template <typename T, int V, int RPT, bool F>
 static bool col_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, hipStream_t s,
                          const void *d_taps)
 {
@@ -1604,7 +1664,7 @@ static bool col_dispatch(const Plane &src, const Plane &dst, int B, const double
 #define SG_COL_CASE(RR)                                                                                               \
     case RR: {                                                                                                        \
         size_t lds = sizeof(T) * (size_t)(TH + 2 * RR) * TW;                                                          \
-        blur_col_k<T, RR, V, RPT><<<g, 256, lds, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, \
+        blur_col_k<T, RR, V, RPT, F><<<g, 256, lds, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, \
                                                       src.img_stride, dst.img_stride, padded_taps<T>(taps, n, RR));   \
     } break;
     switch (R) {
@@ -1615,13 +1675,13 @@ static bool col_dispatch(const Plane &src, const Plane &dst, int B, const double
         SG_COL_CASE(13)
     default: {
         if (d_taps) {
-            blur_col_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
+            blur_col_any_k<T, F><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
                                                  src.img_stride, dst.img_stride, (const T *)d_taps, n);
         } else {
             T *dt = upload_taps<T>(taps, n, s);
             if (!dt)
                 return false; // no device memory for the taps (or more taps than the any-radius kernels take)
-            blur_col_any_k<T><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
+            blur_col_any_k<T, F><<<g2, 256, 0, s>>>((const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch,
                                                  src.img_stride, dst.img_stride, dt, n);
             hipStreamSynchronize(s);
             hipFree(dt);
@@ -1679,7 +1739,7 @@ static bool blur_use_ring(int R, size_t elem)
     return env().blur_mode == 2;
 }
 
-template <typename T, int V>
+template <typename T, int V, bool F>
 static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const double *taps, int n, const Plane *dec,
                            hipStream_t s)
 {
@@ -1727,17 +1787,18 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
     T *dec_p = dec ? (T *)dec->p : nullptr;
     const int dec_rows = dec ? dec->rows : 0, dec_cols = dec ? dec->cols : 0, dec_pitch = dec ? dec->pitch : 0;
     const size_t dec_img = dec ? dec->img_stride : 0;
-    dim3 g((strips + 3) / 4, nseg, B);
+    const TileGrid tg = {(strips + 3) / 4, nseg, B, env().blur_remap};
+    const dim3 g = tile_launch_grid(tg);
 #define SG_WIN_CASE(RR)                                                                                               \
     case RR:                                                                                                          \
         if (dma)                                                                                                      \
-            blur_dma_k<T, RR, V><<<g, 256, 4 * WinDma<T, RR, V>::WAVE_BYTES, s>>>(                                    \
+            blur_dma_k<T, RR, V, F><<<g, 256, 4 * WinDma<T, RR, V>::WAVE_BYTES, s>>>(                                 \
                 (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
-                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                          \
+                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img, tg);                      \
         else                                                                                                          \
-            blur_win_k<T, RR, V><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                                           \
+            blur_win_k<T, RR, V, false, false, F><<<g, 256, win_lds_bytes<T, RR, V>(), s>>>(                          \
                 (const T *)src.p, (T *)dst.p, rows, cols, src.pitch, dst.pitch, src.img_stride, dst.img_stride, seg,  \
-                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img);                          \
+                padded_taps<T>(taps, n, RR), dec_p, dec_rows, dec_cols, dec_pitch, dec_img, tg);                      \
         break;
     switch (R) {
         SG_WIN_CASE(5)
@@ -1754,7 +1815,7 @@ static bool fused_dispatch(const Plane &src, const Plane &dst, int B, const doub
 
 // Upsampling form: `gray` is a double plane of dst.rows/2 x dst.cols/2; dst = blur(UpSample(gray)).  Instantiated
 // for the radius of the pyramid's base blur only.
-template <typename T, int V>
+template <typename T, int V, bool F>
 static bool ups_dispatch(const Plane &gray, const Plane &dst, int B, const double *taps, int n, hipStream_t s)
 {
     constexpr int R = 5;
@@ -1767,19 +1828,20 @@ static bool ups_dispatch(const Plane &gray, const Plane &dst, int B, const doubl
     const long long per_row = (long long)strips * B;
     const int seg = win_segment_rows(rows, per_row, R, win_waves_per_simd(R));
     const int nseg = (rows + seg - 1) / seg;
-    dim3 g((strips + 3) / 4, nseg, B);
+    const TileGrid tg = {(strips + 3) / 4, nseg, B, env().blur_remap};
+    const dim3 g = tile_launch_grid(tg);
     // gray rows staged by direct-to-LDS loads when they are 16-byte aligned (SIFTGPU_BLUR_DIRECT=1: loaded by the lanes)
     const bool gdma = !env().blur_direct && (uintptr_t)gray.p % 16 == 0 && gray.pitch % 2 == 0 &&
                       gray.pitch >= 2 && (gray.img_stride * sizeof(double)) % 16 == 0;
     if (gdma)
-        blur_win_k<T, R, V, true, true>
+        blur_win_k<T, R, V, true, true, F>
             <<<g, 256, ((win_lds_bytes<T, R, V>() + 15) & ~(size_t)15) + 4 * WinGray<T, R, V>::WAVE_BYTES, s>>>(
                 (const T *)gray.p, (T *)dst.p, rows, cols, gray.pitch, dst.pitch, gray.img_stride, dst.img_stride, seg,
-                padded_taps<T>(taps, n, R), nullptr, 0, 0, 0, 0);
+                padded_taps<T>(taps, n, R), nullptr, 0, 0, 0, 0, tg);
     else
-        blur_win_k<T, R, V, true><<<g, 256, win_lds_bytes<T, R, V>(), s>>>(
+        blur_win_k<T, R, V, true, false, F><<<g, 256, win_lds_bytes<T, R, V>(), s>>>(
             (const T *)gray.p, (T *)dst.p, rows, cols, gray.pitch, dst.pitch, gray.img_stride, dst.img_stride, seg,
-            padded_taps<T>(taps, n, R), nullptr, 0, 0, 0, 0);
+            padded_taps<T>(taps, n, R), nullptr, 0, 0, 0, 0, tg);
     return true;
 }
 
@@ -1788,23 +1850,28 @@ bool launch_blur_fused_upsampled(const Plane &gray, const Plane &dst, int B, con
 {
     if (env().blur_mode == 1 || env().blur_mode == 2)
         return false; // another variant is forced
-    if (prec == SG_F64)
-        return ups_dispatch<double, 2>(gray, dst, B, taps, n, s);
-    return ups_dispatch<float, 4>(gray, dst, B, taps, n, s);
+    if (prec_store(prec) != SG_F64)
+        return ups_dispatch<float, 4, false>(gray, dst, B, taps, n, s);
+    return prec_fma(prec) ? ups_dispatch<double, 2, true>(gray, dst, B, taps, n, s)
+                          : ups_dispatch<double, 2, false>(gray, dst, B, taps, n, s);
 }
 
 bool launch_blur_fused(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
                        const Plane *dec)
 {
-    if (prec == SG_F64)
-        return fused_dispatch<double, 2>(src, dst, B, taps, n, dec, s);
-    return fused_dispatch<float, 4>(src, dst, B, taps, n, dec, s);
+    if (prec_store(prec) != SG_F64)
+        return fused_dispatch<float, 4, false>(src, dst, B, taps, n, dec, s);
+    return prec_fma(prec) ? fused_dispatch<double, 2, true>(src, dst, B, taps, n, dec, s)
+                          : fused_dispatch<double, 2, false>(src, dst, B, taps, n, dec, s);
 }
 
 // Levels a and b = blur(a) of one plane in one launch (blur_pair_k): for the 11- and 13-tap pair of the pyramid's
 // levels 1 and 2, rows staged by LDS-DMA, and launches whose segments are long enough that the RA + RB rows a segment
 // starts early do not matter.  False (nothing launched) otherwise: the caller then blurs level by level.
-template <typename T, int V>
+// (The 21- and 27-tap pair of levels 4 and 5 was measured too: its two register windows need more than the 256
+// registers of two waves per SIMD -- 85 ms per 256 frames with the spills, 35 ms at one wave per SIMD, against 19.5 ms
+// for the two single-level launches -- so the wide levels stay apart.)
+template <typename T, int V, bool F>
 static bool pair_dispatch(const Plane &src, const Plane &dst_a, const Plane &dst_b, int B, const double *taps_a, int n_a,
                           const double *taps_b, int n_b, hipStream_t s)
 {
@@ -1823,41 +1890,44 @@ static bool pair_dispatch(const Plane &src, const Plane &dst_a, const Plane &dst
     if (seg < 8 * P::LEAD && seg < rows && env().blur_pair != 2)
         return false; // short segments: the early rows would be a large share of the work
     const int nseg = (rows + seg - 1) / seg;
-    dim3 g((strips + 3) / 4, nseg, B);
-    blur_pair_k<T, RA, RB, V><<<g, 256, 4 * P::WAVE_BYTES, s>>>(
+    const TileGrid tg = {(strips + 3) / 4, nseg, B, env().blur_remap};
+    blur_pair_k<T, RA, RB, V, F><<<tile_launch_grid(tg), 256, 4 * P::WAVE_BYTES, s>>>(
         (const T *)src.p, (T *)dst_a.p, (T *)dst_b.p, rows, cols, src.pitch, dst_a.pitch, dst_b.pitch, src.img_stride,
-        dst_a.img_stride, dst_b.img_stride, seg, padded_taps<T>(taps_a, n_a, RA), padded_taps<T>(taps_b, n_b, RB));
+        dst_a.img_stride, dst_b.img_stride, seg, padded_taps<T>(taps_a, n_a, RA), padded_taps<T>(taps_b, n_b, RB), tg);
     return true;
 }
 
 bool launch_blur_pair(const Plane &src, const Plane &dst_a, const Plane &dst_b, int B, const double *taps_a, int n_a,
                       const double *taps_b, int n_b, int prec, hipStream_t s)
 {
-    if (prec == SG_F64)
-        return pair_dispatch<double, 2>(src, dst_a, dst_b, B, taps_a, n_a, taps_b, n_b, s);
-    return pair_dispatch<float, 4>(src, dst_a, dst_b, B, taps_a, n_a, taps_b, n_b, s);
+    if (prec_store(prec) != SG_F64)
+        return pair_dispatch<float, 4, false>(src, dst_a, dst_b, B, taps_a, n_a, taps_b, n_b, s);
+    return prec_fma(prec) ? pair_dispatch<double, 2, true>(src, dst_a, dst_b, B, taps_a, n_a, taps_b, n_b, s)
+                          : pair_dispatch<double, 2, false>(src, dst_a, dst_b, B, taps_a, n_a, taps_b, n_b, s);
 }
 
 bool blur_fused_decimates(const Plane &src, int n, int prec)
 {
     return blur_fused_supported(src, n) && src.rows > 1 && src.cols > 1 &&
-           !blur_use_ring(bucket_radius(n / 2), prec == SG_F64 ? 8 : 4);
+           !blur_use_ring(bucket_radius(n / 2), prec_store(prec) == SG_F64 ? 8 : 4);
 }
 
 bool launch_blur_row(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
                      const void *d_taps)
 {
-    if (prec == SG_F64)
-        return row_dispatch<double, 2, 2>(src, dst, B, taps, n, s, d_taps);
-    return row_dispatch<float, 4, 1>(src, dst, B, taps, n, s, d_taps);
+    if (prec_store(prec) != SG_F64)
+        return row_dispatch<float, 4, 1, false>(src, dst, B, taps, n, s, d_taps);
+    return prec_fma(prec) ? row_dispatch<double, 2, 2, true>(src, dst, B, taps, n, s, d_taps)
+                          : row_dispatch<double, 2, 2, false>(src, dst, B, taps, n, s, d_taps);
 }
 
 bool launch_blur_col(const Plane &src, const Plane &dst, int B, const double *taps, int n, int prec, hipStream_t s,
                      const void *d_taps)
 {
-    if (prec == SG_F64)
-        return col_dispatch<double, 2, 8>(src, dst, B, taps, n, s, d_taps);
-    return col_dispatch<float, 4, 8>(src, dst, B, taps, n, s, d_taps);
+    if (prec_store(prec) != SG_F64)
+        return col_dispatch<float, 4, 8, false>(src, dst, B, taps, n, s, d_taps);
+    return prec_fma(prec) ? col_dispatch<double, 2, 8, true>(src, dst, B, taps, n, s, d_taps)
+                          : col_dispatch<double, 2, 8, false>(src, dst, B, taps, n, s, d_taps);
 }
 
 } // namespace sg

@@ -32,11 +32,18 @@ struct Env {
     bool blur_direct = false, detect_direct = false;
     int blur_pair = 1; // SIFTGPU_BLUR_PAIR: 0 levels 1 and 2 always as two launches, 1 one launch where segments are
                        // long (default), 2 one launch wherever the plane is large enough (tests)
+    int blur_remap = 0;                 // SIFTGPU_BLUR_REMAP=1: XCD-aware tile order of the strip-walking blur launches
     bool pyr_tail = true;               // SIFTGPU_PYR_TAIL=0: the smallest octaves level by level, like the large ones
     int ori_waves = 0, descr_waves = 0; // 0 = library default
     int n_cu = 256;                     // compute units of the current device at first use
 };
 const Env &env();
+
+// The `prec` argument of the blur launchers: an sg_precision (the pyramid's storage type) in the low byte, and
+// kPrecFma where the double filters take fused multiply-adds (sg_params.precision = SG_F64_FMA).
+constexpr int kPrecFma = 0x100;
+inline int prec_store(int prec) { return prec & 0xff; }
+inline bool prec_fma(int prec) { return (prec & kPrecFma) != 0; }
 
 // One image plane (or a batch of them): element pointer, geometry in elements.
 struct Plane {

@@ -38,6 +38,8 @@ __device__ __forceinline__ void wait_groups_ahead(int ahead)
 
 // 16 bytes per active lane from base + voff (bytes) to LDS at lds_dst + 16 * lane; lds_dst and base wave-uniform.
 // M0 belongs to the compiler outside the statement, so it is saved and restored.
+// (The non-temporal form of the load, `nt`, was measured on the blur and extrema kernels: their own times stay the
+// same or grow by 3-10 %, and the kernels that read the same planes afterwards slow down several-fold; not used.)
 __device__ __forceinline__ void load16_to_lds(unsigned int lds_dst, unsigned long long base, unsigned int voff)
 {
     unsigned int keep;

@@ -35,6 +35,8 @@ const Env &env()
             v.blur_pair = strcmp(pr, "0") == 0 ? 0 : (strcmp(pr, "2") == 0 ? 2 : 1);
         if (const char *t = getenv("SIFTGPU_PYR_TAIL"))
             v.pyr_tail = strcmp(t, "0") != 0;
+        if (const char *t = getenv("SIFTGPU_BLUR_REMAP"))
+            v.blur_remap = strcmp(t, "0") != 0;
         if (const char *w = getenv("SIFTGPU_ORI_WAVES"))
             v.ori_waves = atoi(w);
         if (const char *w = getenv("SIFTGPU_DESCR_WAVES"))
@@ -176,6 +178,8 @@ struct sg_ctx {
     int tail_octave = 0;           // first octave of the last call produced by the pyramid-tail launch (octaves: none)
     bool launch_failed = false; // a blur could not be launched (its taps found no device memory)
     bool fused_blur = true; // one-launch blur; SIFTGPU_BLUR=2pass selects the separate row/column kernels
+    bool blur_fma = false;  // SG_F64_FMA: the double filters take fused multiply-adds (prm.precision then reads SG_F64)
+    int blur_prec() const { return prm.precision | (blur_fma ? kPrecFma : 0); } // what the blur launchers are handed
     StageEvents ev;
     double stage_ms[SG_ST_COUNT];
     unsigned long long stage_launches[SG_ST_COUNT];
@@ -519,8 +523,8 @@ static bool blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, co
 {
     if (c->fused_blur && blur_fused_supported(src, n)) {
         StageScope sc(c, SG_ST_BLUR_COL0 + slot);
-        const bool with_dec = dec && blur_fused_decimates(src, n, c->prm.precision);
-        if (launch_blur_fused(src, dst, B, taps, n, c->prm.precision, side ? side : c->stream, with_dec ? dec : nullptr))
+        const bool with_dec = dec && blur_fused_decimates(src, n, c->blur_prec());
+        if (launch_blur_fused(src, dst, B, taps, n, c->blur_prec(), side ? side : c->stream, with_dec ? dec : nullptr))
             return with_dec;
     }
     Plane tmp = src;
@@ -532,12 +536,12 @@ static bool blur_planes(sg_ctx *c, const Plane &src, const Plane &dst, int B, co
     const void *d_taps = taps == c->taps[slot] ? c->d_taps[slot] : nullptr; // the context's own levels only
     {
         StageScope sc(c, SG_ST_BLUR_ROW0 + slot);
-        if (!launch_blur_row(src, tmp, B, taps, n, c->prm.precision, c->stream, d_taps))
+        if (!launch_blur_row(src, tmp, B, taps, n, c->blur_prec(), c->stream, d_taps))
             c->launch_failed = true;
     }
     {
         StageScope sc(c, (c->fused_blur ? SG_ST_BLUR_ROW0 : SG_ST_BLUR_COL0) + slot);
-        if (!launch_blur_col(tmp, dst, B, taps, n, c->prm.precision, c->stream, d_taps))
+        if (!launch_blur_col(tmp, dst, B, taps, n, c->blur_prec(), c->stream, d_taps))
             c->launch_failed = true;
     }
     return false;
@@ -582,7 +586,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
             launch_gray(d_imgs, h, w, ch, stride, img_stride, gray, B, SG_F64, s);
         }
         StageScope sc(c, SG_ST_BLUR_COL0);
-        base_done = launch_blur_fused_upsampled(gray, c->level[0][0], B, c->taps[0], c->ntaps[0], prec, s);
+        base_done = launch_blur_fused_upsampled(gray, c->level[0][0], B, c->taps[0], c->ntaps[0], c->blur_prec(), s);
     }
     if (!base_done) {
         {
@@ -602,7 +606,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
         tail_taps[l - 1] = c->taps[l];
         tail_ntaps[l - 1] = c->ntaps[l];
     }
-    const int tail = c->fused_blur ? pyr_tail_first(c->tab, tail_ntaps, prec) : c->octaves;
+    const int tail = c->fused_blur ? pyr_tail_first(c->tab, tail_ntaps, c->blur_prec()) : c->octaves;
     c->tail_octave = c->octaves;
     // A frame alone: the tail launch keeps one compute unit busy for about as long as the scan of the octaves before
     // it takes on the rest of the chip, so that scan runs beside it, on the side stream behind those octaves' levels 4
@@ -623,7 +627,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
         }
         if (o == tail) { // level 0 of the first tail octave is in place: one launch takes the pyramid from here
             StageScope sc(c, SG_ST_PYR_TAIL);
-            if (launch_pyr_tail(c->tab, tail, B, tail_taps, tail_ntaps, prec, s)) {
+            if (launch_pyr_tail(c->tab, tail, B, tail_taps, tail_ntaps, c->blur_prec(), s)) {
                 c->tail_octave = tail;
                 if (scan_beside_tail && side_octaves == tail) { // every octave before the tail has its levels 4, 5 there
                     launch_detect(c->tab, B, c->d_words, c->words_img, c->d_chunks, c->chunks_total, c->d_ctr,
@@ -647,7 +651,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
             if (l == 1 && c->fused_blur) { // levels 1 and 2 in one launch where that form applies
                 StageScope sc(c, SG_ST_BLUR_PAIR);
                 if (launch_blur_pair(c->level[o][0], c->level[o][1], c->level[o][2], B, c->taps[1], c->ntaps[1], c->taps[2],
-                                     c->ntaps[2], prec, s)) {
+                                     c->ntaps[2], c->blur_prec(), s)) {
                     c->pair_octaves |= 1u << o;
                     l = 2;
                     continue;
@@ -899,11 +903,17 @@ int sg_destroy(sg_ctx *c)
     return SG_OK;
 }
 
-int sg_create(const sg_params *p, sg_ctx **out)
+int sg_create(const sg_params *p_in, sg_ctx **out)
 {
-    if (!p || !out)
+    if (!p_in || !out)
         return SG_E_INVALID;
     *out = nullptr;
+    // SG_F64_FMA is SG_F64 everywhere (storage, keypoint stages) except in the arithmetic of the blur kernels
+    sg_params prm_local = *p_in;
+    const bool blur_fma = prm_local.precision == SG_F64_FMA;
+    if (blur_fma)
+        prm_local.precision = SG_F64;
+    const sg_params *p = &prm_local;
     if (p->intervals != 3)
         return SG_E_UNSUPPORTED;
     if (!(p->sigma > 1.0) || p->max_width < 2 || p->max_height < 2 || p->max_batch < 1)
@@ -930,6 +940,7 @@ int sg_create(const sg_params *p, sg_ctx **out)
     c->B = p->max_batch;
     c->esize = p->precision == SG_F64 ? 8 : 4;
     c->fused_blur = env().blur_mode != 1; // the switches are read here, once per process
+    c->blur_fma = blur_fma;
     memset(c->stage_ms, 0, sizeof c->stage_ms);
     memset(c->stage_launches, 0, sizeof c->stage_launches);
 
@@ -1875,13 +1886,13 @@ int blur_tmp(sg_ctx *c, const Plane &src, const Plane &dst, double sigma)
     int n = gaussian_taps(sigma, taps.data(), 1024);
     if (n < 0)
         return fail(c, SG_E_UNSUPPORTED, "sigma too large");
-    if (c->fused_blur && launch_blur_fused(src, dst, 1, taps.data(), n, c->prm.precision, c->stream))
+    if (c->fused_blur && launch_blur_fused(src, dst, 1, taps.data(), n, c->blur_prec(), c->stream))
         return finish(c);
     TmpPlane tmp(c, src.rows, src.cols);
     if (!tmp.ok())
         return fail(c, SG_E_NOMEM, "out of device memory");
-    if (!launch_blur_row(src, tmp.pl, 1, taps.data(), n, c->prm.precision, c->stream) ||
-        !launch_blur_col(tmp.pl, dst, 1, taps.data(), n, c->prm.precision, c->stream))
+    if (!launch_blur_row(src, tmp.pl, 1, taps.data(), n, c->blur_prec(), c->stream) ||
+        !launch_blur_col(tmp.pl, dst, 1, taps.data(), n, c->blur_prec(), c->stream))
         return fail(c, SG_E_NOMEM, "out of device memory (blur taps)");
     return finish(c);
 }

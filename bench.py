@@ -467,6 +467,8 @@ def main():
         else:
             exchange = "torch.distributed all-gather-v (%s rehearsal)" % dist.get_backend()
     gathered_total = [0] * nbuf   # features in the gathered buffer b
+    gathered_first = [None] * nbuf  # rank_first of the gathered buffer b (index of each rank's first feature)
+    gathered_v = [None] * nbuf      # (features, counts) of buffer b when the exchange went through torch.distributed
     gather_busy = [False] * nbuf  # all-gather in flight on buffer b
     pending = [None] * nctx       # buffer that context c's batch in flight writes
 
@@ -489,12 +491,15 @@ def main():
                 first = xctx.allgather_features(comm, outs[b].data_ptr(), cnts[b].data_ptr(), B, cap,
                                                 g_outs[b].data_ptr(), cap_all, g_cnts[b].data_ptr(), world)
                 gathered_total[b] = first[-1]
+                gathered_first[b] = first
                 gather_busy[b] = True
             else:
                 on_dev = dist.get_backend() == "nccl"
                 gv, gc, first = sdist.allgather_features_v(outs[b] if on_dev else outs[b].cpu(),
                                                            cnts[b] if on_dev else cnts[b].cpu(), cap)
                 gathered_total[b] = first[-1]
+                gathered_first[b] = first
+                gathered_v[b] = (gv, gc)
 
     def submit(step):
         c, b = step % nctx, step % nbuf
@@ -559,6 +564,53 @@ def main():
     gathered_last = gathered_total[last_buf[0]] if do_exchange else None
 
     last_first = ((WU + K - 1) * B) % pool  # first frame of the last step's batch
+
+    # ---- the exchange checks itself (outside the timed region, every rank) ----
+    # A wrong slot offset or a slot that never arrived would still print a throughput number, so the last step's
+    # gathered buffer is verified on every rank: (1) this rank's slot equals its own features, compacted by
+    # sg_compact_features; (2) the gathered counts equal an all-gather of the ranks' counts through torch.distributed;
+    # (3) a position-weighted 64-bit checksum of the whole gathered buffer is the same on every rank.  Valid because
+    # a frame's features are a pure function of its pixels (reference sift/sift.cpp:1646-1707).
+    exchange_check = None
+    if do_exchange:
+        b = last_buf[0]
+        first = gathered_first[b]
+        on_dev = world == 1 or dist.get_backend() == "nccl"
+        if xctx is not None:
+            g_feat, g_cnt = g_outs[b], g_cnts[b]
+        else:
+            g_feat, g_cnt = gathered_v[b][0], gathered_v[b][1].reshape(-1)
+        total = int(first[-1])
+        mine = int(first[rank + 1] - first[rank])
+        local_cnt = cnts[b] if on_dev else cnts[b].cpu()
+        # (1) own slot
+        tmp = torch.empty(max(mine, 1) * 144, dtype=torch.uint8, device=dev)
+        ctxs[0].compact_features(outs[b].data_ptr(), cnts[b].data_ptr(), B, cap, tmp.data_ptr())
+        ctxs[0].sync()
+        own = g_feat[first[rank] * 144: first[rank + 1] * 144]
+        own_ok = mine == int(local_cnt.clamp(max=cap).sum().item()) and \
+            torch.equal(own.to(tmp.device), tmp[: mine * 144])
+        # (2) counts
+        if world > 1:
+            want_cnt = torch.empty(world * B, dtype=local_cnt.dtype, device=local_cnt.device)
+            dist.all_gather_into_tensor(want_cnt, local_cnt.reshape(-1).contiguous())
+        else:
+            want_cnt = local_cnt.reshape(-1)
+        counts_ok = torch.equal(want_cnt.cpu().to(torch.int64), g_cnt.reshape(-1).cpu().to(torch.int64))
+        # (3) checksum over all ranks' features
+        words = g_feat[: total * 144].view(torch.int64)
+        weights = torch.arange(words.numel(), dtype=torch.int64, device=words.device) * 2654435761 + 1
+        cs = int((words * weights).sum().item()) if total else 0
+        cs_t = torch.tensor([cs, -cs, 1 if (own_ok and counts_ok) else 0], dtype=torch.int64,
+                            device=dev if on_dev else "cpu")
+        if world > 1:
+            dist.all_reduce(cs_t, op=dist.ReduceOp.MIN)
+        checksum_equal = int(cs_t[0].item()) == -int(cs_t[1].item())
+        exchange_check = {"ok": bool(cs_t[2].item()) and checksum_equal, "ranks": world, "features_gathered": total,
+                          "own_slot_equal": bool(own_ok), "counts_equal": bool(counts_ok),
+                          "all_ranks_own_slot_and_counts_ok": bool(cs_t[2].item()), "checksum_equal": checksum_equal,
+                          "checksum": "%016x" % (cs & 0xffffffffffffffff)}
+        del tmp
     for c in ctxs:
         c.close()
     if xctx is not None:
@@ -569,6 +621,8 @@ def main():
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
+        if exchange_check is not None and not exchange_check["ok"]:
+            sys.exit("bench.py rank %d: the gathered feature sets failed their check: %s" % (rank, json.dumps(exchange_check)))
         return
     verify = latency = host_api = None
     if not args.no_extras:
@@ -745,7 +799,7 @@ def main():
             valu_roofline("descr_k<double,false>", work[0], stage_ms.get("descr", 0.0) / K) if esize == 8 else None,
             valu_roofline("orient_k<double,false>", work[1], stage_ms.get("orient", 0.0) / K) if esize == 8 else None) if r],
         "batch_check": verify, "latency_ms": latency, "host_api": host_api,
-        "two_batches_in_flight": overlap, "f64_fma": f64_fma, "exchange": exchange,
+        "two_batches_in_flight": overlap, "f64_fma": f64_fma, "exchange": exchange, "exchange_check": exchange_check,
         "features_last_step": int(feat_counts.astype(np.int64).sum()), "features_gathered_last_step": gathered_last,
         "stage_ms_per_step": {k: v / K for k, v in stage_ms.items() if v > 0},
         "blur_kernels": blur, "detect_kernel": detect,
@@ -753,6 +807,8 @@ def main():
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+    if exchange_check is not None and not exchange_check["ok"]:
+        sys.exit("bench.py: the gathered feature sets failed their check: %s" % json.dumps(exchange_check))
 
 
 if __name__ == "__main__":

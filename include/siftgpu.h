@@ -293,9 +293,16 @@ int sg_match_packed_device_noalloc(sg_ctx *ctx, const sg_packed_feature *d_f1, u
  * rank's first feature in d_all (rank_first[n_ranks] = total).  SG_E_CAPACITY when the total exceeds cap_all.
  * `comm` is an RCCL communicator (ncclComm_t, passed as void* so that this header needs no rccl.h) created by the
  * caller or by sg_comm_create; NULL means a single rank (no RCCL call is made).  The counts are all-gathered and read
- * by the host (one stream synchronisation); the features then move as one grouped set of ncclBroadcast calls,
+ * by the host (stream synchronisations); the features then move as one grouped set of ncclBroadcast calls,
  * asynchronous on the context's stream (sg_sync waits).  Call it on a context whose stream is not the one a next
- * batch is being extracted on if the exchange is to overlap that extraction. */
+ * batch is being extracted on if the exchange is to overlap that extraction.
+ * Errors are decided by all ranks together where they can be: the ranks first exchange (cap_all, n_img,
+ * cap_per_image); differing n_img or cap_per_image give SG_E_INVALID on every rank, and the capacity test uses the
+ * smallest cap_all, so SG_E_CAPACITY is returned by every rank or by none and no rank is left waiting in a
+ * collective.  Any other failure (SG_E_HIP: a HIP or RCCL error on one rank) cannot be agreed on: after it the
+ * communicator must be destroyed, and the other ranks' calls may not return.
+ * The path with more than one rank needs one GPU per rank; it has been exercised on multi-GPU hardware only through
+ * bench.py's self-check (exchange_check), which every multi-rank run performs. */
 #define SG_COMM_ID_BYTES 128
 int sg_comm_unique_id(void *id /* SG_COMM_ID_BYTES, filled on one rank and handed to all */);
 int sg_comm_create(sg_ctx *ctx, const void *id, int rank, int n_ranks, void **comm); /* on ctx's device */

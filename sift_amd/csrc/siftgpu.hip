@@ -97,6 +97,7 @@ unsigned char *static_scratch_for(int device, hipError_t *err)
 }
 
 constexpr int kEventPairs = 4096;
+constexpr int kMaxCommRanks = 1024; // ranks sg_allgather_features sizes its header buffer for
 
 struct StageEvents {
     hipEvent_t start[kEventPairs], stop[kEventPairs];
@@ -127,6 +128,7 @@ struct sg_ctx {
     void *d_mpart = nullptr; // per-slice partial results of the matcher
     size_t mpart_bytes = 0;
     unsigned char *static_scratch = nullptr; // this device's copy of the allocation-free matcher's scratch array
+    uint32_t *d_xhdr = nullptr; // sg_allgather_features: this rank's four header words, then every rank's
 
     // geometry of the current call
     int w = 0, h = 0, octaves = 0, last_batch = 0;
@@ -395,6 +397,15 @@ static int set_geometry(sg_ctx *c, int w, int h, int B)
 
 // ---- keypoint stages (shared by the whole path and the stage entry points) ------------------------------
 
+// The working buffers (keypoints, feature lists, descriptors, ranks, counts) are about to be overwritten: what an
+// earlier sg_extract_begin / sg_extract_batch_begin left for its fetch call is gone, and a fetch must say so rather
+// than pack records from the new contents with the old counts.
+static void invalidate_pending(sg_ctx *c)
+{
+    c->have_pending = false;
+    c->pending_counts.clear();
+}
+
 constexpr double kDetectThreshold = 0.5 * 0.03 / 3; // 0.5 * DXTHRESHOLD / intervals (sift.cpp:924)
 
 // What a call starts from zero: chunk sums, counters and counts are one region, one fill.
@@ -557,6 +568,7 @@ static int run_pipeline(sg_ctx *c, const uint8_t *d_imgs, int B, int w, int h, i
     hipStream_t s = c->stream;
     const int prec = c->prm.precision;
     c->launch_failed = false;
+    invalidate_pending(c);
     // d_overflow is not cleared here: the words are sticky until check_overflow has read them, so that a second batch
     // enqueued before sg_sync cannot erase the first one's report
     if (c->octaves == 0) {
@@ -874,7 +886,7 @@ int sg_destroy(sg_ctx *c)
         if (b)
             (void)hipFree(b);
     void *mbufs[] = {c->d_mrows[0], c->d_mrows[1], c->d_mnorm[0], c->d_mnorm[1], c->d_mbad, c->d_mpart,
-                     c->d_taps[0], c->d_taps[1], c->d_taps[2], c->d_taps[3], c->d_taps[4], c->d_taps[5]};
+                     c->d_taps[0], c->d_taps[1], c->d_taps[2], c->d_taps[3], c->d_taps[4], c->d_taps[5], c->d_xhdr};
     for (void *b : mbufs)
         if (b)
             (void)hipFree(b);
@@ -1778,6 +1790,36 @@ int sg_allgather_features(sg_ctx *c, void *comm, const sg_packed_feature *d_feat
             return SG_E_HIP;
         }
     }
+    // 0. the ranks agree on the call's shape before any of them depends on it: a four-word header per rank (cap_all,
+    // n_img, cap_per_image) is all-gathered first.  Every rank then sees the same headers and takes the same decision:
+    // differing n_img or cap_per_image -> SG_E_INVALID everywhere (the counts all-gather below would not match up);
+    // the capacity test of step 2 uses the smallest cap_all of all ranks, so that either every rank enters the
+    // broadcasts or none does.  (A HIP or RCCL error on one rank alone cannot be agreed on: after any other non-OK
+    // return the communicator must be taken as broken and destroyed.)
+    size_t cap_all_min = cap_all;
+    if (comm) {
+        if (!c->d_xhdr)
+            HIPCHK(c, hipMalloc((void **)&c->d_xhdr, sizeof(uint32_t) * 4 * (size_t)(kMaxCommRanks + 1)));
+        if (n_ranks > kMaxCommRanks)
+            return fail(c, SG_E_UNSUPPORTED, "more ranks than sg_allgather_features takes");
+        uint32_t hdr[4] = {(uint32_t)(cap_all & 0xffffffffu), (uint32_t)((unsigned long long)cap_all >> 32), (uint32_t)n_img,
+                           (uint32_t)std::min<size_t>(cap_per_image, 0xffffffffu)};
+        HIPCHK(c, hipMemcpyAsync(c->d_xhdr, hdr, sizeof hdr, hipMemcpyHostToDevice, s));
+        int rc = rccl_allgather_u32(comm, c->d_xhdr, c->d_xhdr + 4, 4, s);
+        if (rc != 0) {
+            c->err = std::string("ncclAllGather (header): ") + rccl_error_string(rc);
+            return SG_E_HIP;
+        }
+        std::vector<uint32_t> all_hdr(4 * (size_t)n_ranks);
+        HIPCHK(c, hipMemcpyAsync(all_hdr.data(), c->d_xhdr + 4, sizeof(uint32_t) * all_hdr.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        for (int r = 0; r < n_ranks; r++) {
+            const uint32_t *h = &all_hdr[4 * (size_t)r];
+            if (h[2] != hdr[2] || h[3] != hdr[3])
+                return fail(c, SG_E_INVALID, "the ranks disagree on n_img or cap_per_image");
+            cap_all_min = std::min<size_t>(cap_all_min, (size_t)(((unsigned long long)h[1] << 32) | h[0]));
+        }
+    }
     // 1. every rank learns every frame's count
     if (comm) {
         const int rc = rccl_allgather_u32(comm, d_counts, d_all_counts, (size_t)n_img, s);
@@ -1802,8 +1844,8 @@ int sg_allgather_features(sg_ctx *c, void *comm, const sg_packed_feature *d_feat
     }
     for (int r = 0; r <= n_ranks; r++)
         first_byte[r] = rank_first[r] * sizeof(sg_packed_feature);
-    if (rank_first[n_ranks] > cap_all)
-        return fail(c, SG_E_CAPACITY, "gathered features do not fit cap_all");
+    if (rank_first[n_ranks] > cap_all_min) // the same verdict on every rank
+        return fail(c, SG_E_CAPACITY, "gathered features do not fit the smallest cap_all of the ranks");
     // 3. this rank's features into its own slot, without padding; 4. every slot from its owner
     launch_compact_feats(d_feats, d_counts, n_img, cap_per_image, d_all + rank_first[rank], s);
     HIPCHK(c, hipGetLastError());
@@ -2145,6 +2187,7 @@ int sg_detect_local_extrema(sg_ctx *c, const double *const *dog, int width, int 
         return rc;
     if (pyr.n_words > c->words_img)
         return fail(c, SG_E_CAPACITY, "pyramid larger than the context was sized for");
+    invalidate_pending(c);
     detect_phase(c, pyr.tab, pyr.n_words, 1, nointerval);
     rc = check_overflow(c);
     if (rc != SG_OK)
@@ -2252,6 +2295,7 @@ int sg_orientation_assignment(sg_ctx *c, const sg_keypoint *extrema, size_t n_ex
     int max_radius = 0;
     for (size_t i = 0; i < n_extrema; i++)
         max_radius = std::max(max_radius, ori_radius(extrema[i].octave_scale));
+    invalidate_pending(c);
     orient_phase(c, pyr.tab, 1, max_radius);
     rc = check_overflow(c);
     if (rc != SG_OK)
@@ -2293,6 +2337,7 @@ int sg_descriptor_representation(sg_ctx *c, sg_keypoint *features, size_t n, con
     int max_radius = 0;
     for (size_t i = 0; i < n; i++)
         max_radius = std::max(max_radius, descr_radius(features[i].octave_scale));
+    invalidate_pending(c);
     descr_phase(c, pyr.tab, 1, max_radius);
     rc = finish(c);
     if (rc != SG_OK || !n)
@@ -2323,6 +2368,7 @@ int sg_sort_features(sg_ctx *c, sg_keypoint *features, size_t n)
     HIPCHK(c, hipMemcpyAsync(c->d_fscale, sc.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_counts + 2 * c->B, &cnt, sizeof cnt, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    invalidate_pending(c);
     rank_phase(c, 1);
     int rc = finish(c);
     if (rc != SG_OK)

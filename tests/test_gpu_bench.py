@@ -34,3 +34,34 @@ def test_bench_small_workload():
     # the exchange step ran through the C ABI (a communicator of one rank) and gathered this rank's features unpadded
     assert "sg_allgather_features" in line["exchange"]
     assert line["features_gathered_last_step"] == line["features_last_step"] > 0
+    # ... and checked itself: own slot, counts, checksum
+    chk = line["exchange_check"]
+    assert chk["ok"] is True and chk["ranks"] == 1 and chk["features_gathered"] == line["features_last_step"]
+    assert chk["own_slot_equal"] and chk["counts_equal"] and chk["checksum_equal"]
+    # the tolerance mode beside the headline: same keypoints and bins on value-noise frames (640x480 here, so the
+    # throughput half of the key, which is measured at 1080p, is absent)
+    assert line["f64_fma"] is None or line["f64_fma"].get("bins_identical") in (True, False)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_rehearsal_checks_the_exchange():
+    """The N > 1 control flow of bench.py on the one GPU of the test box: two ranks launched as the driver launches
+    them, sharing the device, the exchange over gloo (RCCL refuses two ranks on one device).  The gathered set of the
+    last step must pass its self-check on both ranks: own slot, counts, checksum equal across ranks."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SIFT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
+           "--warmup", "1", "--batch", "3", "--pool", "6", "--width", "320", "--height", "240", "--cap", "4096",
+           "--no-extras", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and "gloo" in line["exchange"]
+    chk = line["exchange_check"]
+    assert chk["ok"] is True and chk["ranks"] == 2 and chk["checksum_equal"] and chk["counts_equal"] and chk["own_slot_equal"]
+    assert chk["features_gathered"] == line["features_gathered_last_step"] > 2 * 3 * 300

@@ -168,3 +168,32 @@ def test_1080p_seed_sweep_against_oracle(oracle):
     print("1080p sweep: %d features, recall %.6f, descriptors identical %.6f, bins identical %.8f"
           % (total, recall, desc_eq, bin_eq))
     assert recall >= 0.9999 and desc_eq >= 0.9999 and bin_eq >= 0.999999
+
+
+def test_fetch_after_the_buffers_were_reused_is_refused():
+    """sg_extract_begin leaves its records for sg_extract_fetch in the context's working buffers; a batch call (or a
+    stage entry point) in between overwrites them, and the fetch must then fail instead of packing the new contents
+    with the old count."""
+    import ctypes as C
+    import sift_amd
+    from sift_amd import api
+    img = sift_amd.vnoise5(160, 120, 31)
+    other = sift_amd.vnoise5(160, 120, 32)
+    with sift_amd.SiftGPU(max_width=160, max_height=120, max_batch=2) as ctx:
+        L = ctx.lib
+        n = C.c_size_t(0)
+        rc = L.sg_extract_begin(ctx.ctx, img.ctypes.data_as(C.POINTER(C.c_uint8)), 160, 120, 3, 160 * 3, C.byref(n))
+        assert rc == api.SG_OK and n.value > 50
+        recs = np.zeros(n.value, dtype=sift_amd.KEYPOINT_DTYPE)
+        got = C.c_size_t(0)
+        assert L.sg_extract_fetch(ctx.ctx, recs.ctypes.data, n.value, C.byref(got)) == api.SG_OK  # may be fetched twice
+        assert L.sg_extract_fetch(ctx.ctx, recs.ctypes.data, n.value, C.byref(got)) == api.SG_OK
+        ctx.extract_batch(np.stack([other, other]), 4096)  # reuses the working buffers
+        assert L.sg_extract_fetch(ctx.ctx, recs.ctypes.data, n.value, C.byref(got)) == api.SG_E_INVALID
+        # and the same for the batch form's fetch after a single-image call
+        ptrs = (C.POINTER(C.c_uint8) * 2)(img.ctypes.data_as(C.POINTER(C.c_uint8)), other.ctypes.data_as(C.POINTER(C.c_uint8)))
+        counts = (C.c_uint32 * 2)()
+        assert L.sg_extract_batch_begin(ctx.ctx, ptrs, 2, 160, 120, 3, 160 * 3, 0, counts) == api.SG_OK
+        ctx.extract(img)
+        wire = np.zeros(counts[0] + counts[1], dtype=sift_amd.WIRE_DTYPE)
+        assert L.sg_extract_batch_fetch_wire(ctx.ctx, wire.ctypes.data, len(wire)) == api.SG_E_INVALID

@@ -484,3 +484,35 @@ print("no tail ok")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
     assert r.returncode == 0 and "no tail ok" in r.stdout, r.stderr[-3000:] + r.stdout[-500:]
+
+
+def test_fma_precision_mode_stays_within_tolerance(oracle):
+    """SG_F64_FMA (fused multiply-adds in the Gaussian filters; reference sift/sift.cpp:323-326 rounds the product and
+    the sum separately): a tolerance mode.  On value-noise frames the pyramid moves by ~1e-16 relative and every
+    discrete result stays what the oracle gives: counters, keypoints, all descriptor bins.  Tolerances written out:
+    levels within 1e-14 absolute (pixel range 0..1), orientation within 1e-9 rad, scale within 1e-12 relative."""
+    import sift_amd
+    img = sift_amd.vnoise5(320, 240, 77)
+    ref = oracle.Debug(img)
+    with sift_amd.SiftGPU(max_width=320, max_height=240, precision=sift_amd.SG_F64_FMA) as ctx, \
+            sift_amd.SiftGPU(max_width=320, max_height=240) as exact:
+        got = ctx.extract(img)
+        assert ctx.read_counters() == ref.counters
+        differs = 0
+        for o in range(ctx.last_octaves()):
+            for l in range(6):
+                lv = ctx.read_level(o, l)
+                assert np.abs(lv - ref.gauss[o * 6 + l]).max() < 1e-14
+                differs += int((lv != ref.gauss[o * 6 + l]).sum())
+        assert differs > 0  # the mode really takes the fused form (the default mode is bit-identical)
+        want = ref.sorted_features
+        assert len(got) == len(want)
+        for f in ("octave", "interval", "x", "y"):
+            assert np.array_equal(got[f], want[f]), f
+        assert np.array_equal(got["descriptor"], want["descriptor"])
+        d = np.abs(got["ori"] - want["ori"])
+        assert np.minimum(d, 2 * np.pi - d).max() < 1e-9
+        assert np.allclose(got["scale"], want["scale"], rtol=1e-12, atol=0)
+        # the default mode beside it: bit-identical levels
+        exact.extract(img)
+        assert np.array_equal(exact.read_level(0, 5), ref.gauss[5])

@@ -13,5 +13,5 @@ objs=""
 for f in siftgpu kernels_image kernels_blur kernels_detect kernels_describe kernels_match sg_comm; do
   if [ "$f.hip" == "$src" ]; then objs="$objs $out/${name}_$f.o"; else objs="$objs $f.o"; fi
 done
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/lib_$name.so $objs -ldl
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $out/lib_$name.so $objs sg_wire.o -ldl
 echo built $out/lib_$name.so

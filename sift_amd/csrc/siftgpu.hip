@@ -788,20 +788,10 @@ static_assert(sizeof(sg_wire_feature) == sizeof(WireRec) && offsetof(sg_wire_fea
                   offsetof(sg_wire_feature, octave_scale) == offsetof(WireRec, oscale),
               "the public wire record is the device's WireRec");
 
+// wire records -> reference-layout records: sg_expand_wire (sg_wire.cpp)
 static void expand_records(const WireRec *w, size_t n, sg_keypoint *out)
 {
-    for (size_t i = 0; i < n; i++) {
-        const WireRec &r = w[i];
-        sg_keypoint &k = out[i];
-        memset(&k, 0, offsetof(sg_keypoint, descriptor)); // padding bytes too: records are byte-reproducible
-        k.octave = r.octave; k.interval = r.interval; k.offset_interval = r.offi;
-        k.x = r.x; k.y = r.y; k.scale = r.scale; k.dx = r.dx; k.dy = r.dy;
-        k.offset_x = r.offx; k.offset_y = r.offy; k.octave_scale = r.oscale; k.ori = r.ori;
-        k.descr_length = 128;
-        for (int q = 0; q < 128; q++)
-            k.descriptor[q] = (double)r.desc[q];
-        k.val = r.val;
-    }
+    sg_expand_wire(reinterpret_cast<const sg_wire_feature *>(w), n, out);
 }
 
 // d_wire: n WireRec records on the device -> out[0..n)
@@ -1291,11 +1281,6 @@ int sg_extract_batch_fetch_wire(sg_ctx *c, sg_wire_feature *out, size_t cap_tota
     return SG_OK;
 }
 
-void sg_expand_wire(const sg_wire_feature *in, size_t n, sg_keypoint *out)
-{
-    if (in && out)
-        expand_records(reinterpret_cast<const WireRec *>(in), n, out);
-}
 
 int sg_host_alloc(size_t bytes, void **ptr)
 {

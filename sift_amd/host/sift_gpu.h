@@ -8,8 +8,8 @@
 //   (defined with external linkage in the reference's sift.cpp:1065-1643 though absent from its header)
 //   and the text feature files (write_features / read_features, sift.cpp:1886-1931).
 //   and the drawing and pyramid-dump helpers (sift.cpp:1772-1884; host code, no GPU involved).
-// Not provided (outside the extraction path): the 8-bit legacy blurs and testInverse3D of the reference
-// (sift.cpp:183-314, 1934-1960).
+// The reference's off-path helpers (the 8-bit legacy blurs and testInverse3D, sift.cpp:183-314, 1934-1960) are
+// declared at the end as plain CPU functions, so that a program that names them still links.
 //
 // Like the reference these functions return void and append to the vectors they are given; a failed
 // GPU call leaves the outputs untouched and is reported by SiftLastStatus() / SiftLastError().

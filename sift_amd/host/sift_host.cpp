@@ -182,6 +182,7 @@ struct Request {
     double sigma = 0;
     int nointerval = 0;
     bool want_counters = false;
+    bool solo = false; // a batch this request was part of failed: it runs again as a batch of one
     // filled by the leader
     bool done = false;
     int rc = SG_OK;
@@ -257,8 +258,10 @@ public:
             const Request *head = queue_.front();
             for (auto it = queue_.begin(); it != queue_.end() && (int)batch.size() < B_;) {
                 const Request *q = *it;
-                if (q->w == head->w && q->h == head->h && q->ch == head->ch && q->sigma == head->sigma &&
-                    q->nointerval == head->nointerval) {
+                const bool joins = q == head || (!head->solo && !q->solo && q->w == head->w && q->h == head->h &&
+                                                 q->ch == head->ch && q->sigma == head->sigma &&
+                                                 q->nointerval == head->nointerval);
+                if (joins) {
                     batch.push_back(*it);
                     it = queue_.erase(it);
                 } else {
@@ -267,7 +270,8 @@ public:
             }
             lk.unlock();
             int wb = -1;
-            std::vector<Request *> back; // requests the context turned out too small for: queued again
+            std::vector<Request *> back; // requests that run again: queued in front of the others
+            failed_ = false;
             try {
                 wb = execute(batch, back);
             } catch (...) { // out of host memory in the bookkeeping: the batch fails, the context stays usable
@@ -277,14 +281,31 @@ public:
                 wb = held_wire_;
             }
             held_wire_ = -1;
+            // A batch of several images failed (one image too dense for any context, no memory left for the whole
+            // batch, ...): the reference serves every call on its own, so one caller's image must not fail another's
+            // call.  Every request of the batch runs again as a batch of one; only the offender keeps the error.
+            std::vector<Request *> finished;
+            if (failed_ && batch.size() > 1) {
+                for (Request *q : batch) {
+                    q->solo = true;
+                    q->rc = SG_OK;
+                    q->error.clear();
+                    q->wire = nullptr;
+                    q->n = 0;
+                    q->wire_buf = -1;
+                    back.push_back(q);
+                }
+            } else {
+                finished = batch;
+            }
             lk.lock();
             if (wb >= 0) {
                 int users = 0;
-                for (Request *q : batch)
+                for (Request *q : finished)
                     users += q->wire_buf == wb;
                 wire_[wb].users = users; // 0: free again at once
             }
-            for (Request *q : batch)
+            for (Request *q : finished)
                 q->done = true;
             queue_.insert(queue_.begin(), back.begin(), back.end());
             busy_ = false;
@@ -295,8 +316,10 @@ public:
     void destroy()
     {
         std::lock_guard<std::mutex> lk(m_);
-        if (ctx_)
-            sg_destroy(ctx_);
+        for (Keyed &k : ctxs_)
+            if (k.ctx)
+                sg_destroy(k.ctx);
+        ctxs_.clear();
         ctx_ = nullptr;
         for (WireBuf &w : wire_) {
             if (w.p)
@@ -322,45 +345,108 @@ private:
         int users = 0; // callers still expanding out of it; -1: held by the leader
     };
 
+    // One context per (sigma, detector) pair in use, so that callers of Sift() and Sift_nointerval(), or callers with
+    // different sigma, who take turns on this lane do not tear a context down and build another on every turn.  At
+    // most kMaxKeyed are kept (each holds a batch's pyramids); the one unused for longest goes first.
+    struct Keyed {
+        sg_ctx *ctx = nullptr;
+        double sigma = 0;
+        int ni = -1;
+        int max_w = 0, max_h = 0, batch = 0;
+        size_t max_features = 0;
+        unsigned long long last_use = 0;
+    };
+    static constexpr size_t kMaxKeyed = 4;
+
+    // makes ctx_ a context for images up to w x h with these parameters and room for min_features features per image
     bool make_context(int w, int h, double sigma, int ni, size_t min_features)
     {
-        const bool fits = ctx_ && w <= max_w_ && h <= max_h_ && sigma == sigma_ && ni == ni_ && min_features <= max_features_;
-        if (fits)
-            return true;
-        if (min_features > max_features_)
-            max_features_ = min_features;
-        if (ctx_)
-            sg_destroy(ctx_);
+        Keyed *k = nullptr;
+        for (Keyed &c : ctxs_)
+            if (c.sigma == sigma && c.ni == ni)
+                k = &c;
+        if (!k) {
+            if (ctxs_.size() >= kMaxKeyed) {
+                size_t oldest = 0;
+                for (size_t i = 1; i < ctxs_.size(); i++)
+                    if (ctxs_[i].last_use < ctxs_[oldest].last_use)
+                        oldest = i;
+                if (ctxs_[oldest].ctx)
+                    sg_destroy(ctxs_[oldest].ctx);
+                ctxs_.erase(ctxs_.begin() + (ptrdiff_t)oldest);
+            }
+            ctxs_.push_back(Keyed());
+            k = &ctxs_.back();
+            k->sigma = sigma;
+            k->ni = ni;
+        }
+        k->last_use = ++use_clock_;
         ctx_ = nullptr;
+        const bool fits = k->ctx && w <= k->max_w && h <= k->max_h && min_features <= k->max_features && k->batch == B_;
+        if (fits) {
+            ctx_ = k->ctx;
+            max_features_ = k->max_features;
+            return true;
+        }
+        if (min_features > k->max_features)
+            k->max_features = min_features;
+        if (k->ctx)
+            sg_destroy(k->ctx);
+        k->ctx = nullptr;
         sg_params p;
         sg_default_params(&p);
         p.sigma = sigma;
         p.nointerval = ni;
-        p.max_width = w > max_w_ ? w : max_w_;
-        p.max_height = h > max_h_ ? h : max_h_;
+        p.max_width = w > k->max_w ? w : k->max_w;
+        p.max_height = h > k->max_h ? h : k->max_h;
         p.device = device_;
-        p.max_features = max_features_ > 0x7fffffff ? 0x7fffffff : (int)max_features_;
-        // a batch of large images may not fit the device (an 8K frame takes 10 GB): fewer images per batch then
+        p.max_features = k->max_features > 0x7fffffff ? 0x7fffffff : (int)k->max_features;
+        // a batch of large images may not fit the device (an 8K frame takes 10 GB): first the other contexts of this
+        // lane go, then fewer images per batch
         for (;;) {
             p.max_batch = B_;
-            if (sg_create(&p, &ctx_) == SG_OK)
+            if (sg_create(&p, &k->ctx) == SG_OK)
                 break;
-            ctx_ = nullptr;
+            k->ctx = nullptr;
+            bool freed = false;
+            for (Keyed &c : ctxs_)
+                if (&c != k && c.ctx) {
+                    sg_destroy(c.ctx);
+                    c.ctx = nullptr;
+                    c.max_w = c.max_h = 0;
+                    freed = true;
+                }
+            if (freed)
+                continue;
             if (B_ <= 1) {
-                max_w_ = max_h_ = 0;
+                k->max_w = k->max_h = 0;
                 return false;
             }
             B_ = (B_ + 1) / 2;
         }
-        max_w_ = p.max_width;
-        max_h_ = p.max_height;
-        sigma_ = sigma;
-        ni_ = ni;
+        k->max_w = p.max_width;
+        k->max_h = p.max_height;
+        k->batch = B_;
+        ctx_ = k->ctx;
+        max_features_ = k->max_features;
         return true;
     }
 
-    static void fail_all(const std::vector<Request *> &batch, int rc, const char *what)
+    // the context in use is dropped (its batch did not fit beside its own transfer buffers)
+    void drop_current_context()
     {
+        for (Keyed &c : ctxs_)
+            if (c.ctx == ctx_ && ctx_) {
+                sg_destroy(c.ctx);
+                c.ctx = nullptr;
+                c.max_w = c.max_h = 0;
+            }
+        ctx_ = nullptr;
+    }
+
+    void fail_all(const std::vector<Request *> &batch, int rc, const char *what)
+    {
+        failed_ = true;
         for (Request *q : batch) {
             q->rc = rc;
             q->error = what && *what ? what : sg_strerror(rc);
@@ -392,8 +478,7 @@ private:
             rc = sg_extract_batch_begin(ctx_, imgs.data(), n, h.w, h.h, h.ch, (size_t)h.w * h.ch, 1, counts.data());
             if (rc == SG_E_NOMEM && B_ > 1) {
                 // the context fitted the device but left no room for the batch's transfer buffers: half the batch
-                sg_destroy(ctx_);
-                ctx_ = nullptr;
+                drop_current_context();
                 B_ = (B_ + 1) / 2;
                 if (!make_context(h.w, h.h, h.sigma, h.nointerval, 0))
                     break;
@@ -476,10 +561,11 @@ private:
     bool busy_ = false;
     const int device_;
     int B_; // images per batch: as asked for, halved while a context of that size does not fit the device
-    sg_ctx *ctx_ = nullptr;
-    int max_w_ = 0, max_h_ = 0, ni_ = -1;
-    double sigma_ = 0;
-    size_t max_features_ = 0;
+    sg_ctx *ctx_ = nullptr;        // the context of the batch being run (one of ctxs_)
+    size_t max_features_ = 0;      // its per-image feature capacity as asked for (0: the library's default)
+    std::vector<Keyed> ctxs_;      // leader only
+    unsigned long long use_clock_ = 0;
+    bool failed_ = false;          // the batch being run was failed as a whole (leader only)
     WireBuf wire_[2];
     int held_wire_ = -1; // wire buffer the running batch has taken (leader only)
     std::vector<Slot> slots_;

@@ -282,6 +282,23 @@ def fma_mode_throughput(args, B):
         return {"error": repr(e)}
 
 
+def host_multi_gpu_driver(W, H, n_gpus, frames):
+    """SiftBatchMultiGpu (host C++, sift_amd/host/sift_multi.cpp): host frames sharded over the GPUs by one thread per
+    GPU, feature sets all-gathered over RCCL, results back on the host -- as a compiled program."""
+    import subprocess
+    exe = os.path.join(ROOT, "sift_amd", "host", "sift_multi_check")
+    if not os.path.exists(exe):
+        return {"error": "%s is not built" % exe}
+    try:
+        p = subprocess.run([exe, "bench", str(W), str(H), str(frames), str(n_gpus), "32"], capture_output=True, text=True,
+                           timeout=240)
+        if p.returncode != 0:
+            return {"error": (p.stderr.strip() or p.stdout.strip())[-300:]}
+        return json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 def two_batches_in_flight(args, B):
     """The same workload with two contexts of half the batch each, so that the histogram kernels of one batch
     (vector-ALU work) run beside the pyramid kernels of the other (memory work).  Kernel durations measured that way no
@@ -324,6 +341,10 @@ def main():
                          "256-frame and the 4096-frames-over-8-GPUs configurations)")
     ap.add_argument("--exchange", action="store_true",
                     help="run the all-gather step on one rank too (a communicator of one; N > 1 always runs it)")
+    ap.add_argument("--host-multi", action="store_true",
+                    help="with several ranks: after the timed region rank 0 also runs the host C++ multi-GPU driver\n"
+                         "(SiftBatchMultiGpu, one process, one thread per GPU) over the same number of GPUs and reports\n"
+                         "its rate under host_api.multi_gpu_driver (on one GPU the extras always include it)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the untimed extras (batch check, single-frame latencies, host-API throughput)")
     ap.add_argument("--cap", type=int, default=26624, help="packed-feature capacity per frame")
@@ -629,6 +650,8 @@ def main():
         verify, latency = batch_check_and_latency(sift_amd, torch, dev, dev_index, prec, W, H, cap, frames, frame_bytes,
                                                   last_first, B, outs[last_buf[0]], feat_counts)
         host_api = host_api_throughput(W, H, dev_index, args.cpu_threads)
+        if world == 1 or args.host_multi:
+            host_api["multi_gpu_driver"] = host_multi_gpu_driver(W, H, world, 128 * world)
     overlap = f64_fma = None
     if not args.no_extras and args.precision == "f64" and (W, H) == (1920, 1080):
         try:

@@ -144,3 +144,28 @@ void SiftReleaseContext();       // free this thread's GPU context
 // transfers overlap the other's kernels; a context whose batch size does not fit the device is created smaller.
 // Call it while no Sift() call is running: it frees the shared contexts.
 void SiftSetBatching(int max_batch);
+
+// ---- a batch of frames over the GPUs of one node ---------------------------------------------------------------------
+// The reference extracts one image per call (sift/源.cpp:21-22 calls Sift() once per image) and a frame's features
+// depend on its pixels alone, so a batch shards by frame: GPU g of G takes frames [g * ceil(F/G), (g+1) * ceil(F/G)),
+// one host thread per GPU, no communication during extraction; then the GPUs all-gather their packed feature sets
+// (RCCL all-gather-v over xGMI: afterwards every GPU holds every frame's features, in frame order) and the host
+// receives them from GPU 0.  features[f] = the features of frames[f], ordered as Sift() orders them, in the packed
+// form of the throughput path: dx, dy, scale, ori as floats and the 128 descriptor values as bytes.
+struct SiftPackedFeature {
+    float x, y, scale, ori;        // Keypoint.dx, .dy, .scale, .ori
+    unsigned char descriptor[128]; // Keypoint.descriptor (integers 0..255)
+};
+struct SiftMultiGpuOptions {
+    int n_gpus = 0;                 // 0: every GPU of the node
+    int batch = 32;                 // frames a GPU extracts per launch sequence (a 1080p frame takes 0.7 GB of pyramid)
+    double sigma = SIGMA;
+    bool nointerval = false;        // Sift_nointerval's detector
+    int max_features_per_frame = 0; // 0: width * height / 40 + 4096; raised (and the shards run again) on overflow
+    bool rehearsal = false;         // ranks share the GPUs present (rank r on GPU r mod G) and their sets meet in host
+                                    // memory instead of RCCL, which refuses two ranks on one GPU: for trying the
+                                    // sharding on a machine with fewer GPUs than ranks
+};
+// Returns 0 (SG_OK) or a negative sg_status; *error (optional) receives the text.
+int SiftBatchMultiGpu(const std::vector<Mat> &frames, std::vector<std::vector<SiftPackedFeature>> &features,
+                      const SiftMultiGpuOptions &options = SiftMultiGpuOptions(), std::string *error = nullptr);

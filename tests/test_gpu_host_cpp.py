@@ -91,3 +91,17 @@ def test_shared_context_shrinks_its_batch_for_8k_frames():
     out = subprocess.run([exe, "shared", "7680", "4320", "5", "1", "16"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr + out.stdout
     assert "shared ok: 5 threads x 1 calls" in out.stdout
+
+
+@pytest.mark.parametrize("frames,gpus,batch,rehearsal", [(7, 1, 3, 0), (7, 3, 2, 1), (2, 4, 8, 1)])
+def test_multi_gpu_driver_equals_sift_per_frame(frames, gpus, batch, rehearsal):
+    """SiftBatchMultiGpu (host C++: frames sharded over GPUs, one thread per GPU, all-gather of the feature sets)
+    against Sift() on every frame: same features in the same order, dense frames (which overflow the default capacity
+    and make every shard run again with a larger one) included.  On the one GPU of the test box: the real path with one
+    rank, and the sharding with several ranks in rehearsal mode (ranks share the GPU, sets meet in host memory; the
+    last shard short, or more ranks than frames)."""
+    exe = _need("sift_multi_check")
+    out = subprocess.run([exe, "check", "320", "240", str(frames), str(gpus), str(batch), str(rehearsal)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "multi ok: %d frames" % frames in out.stdout

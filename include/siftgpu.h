@@ -196,7 +196,11 @@ int sg_half_features(sg_keypoint *kp, size_t n);
 int sg_orientation_assignment(sg_ctx *ctx, const sg_keypoint *extrema, size_t n_extrema,
                               const double *const *gauss, int width, int height, int octaves,
                               sg_keypoint *out, size_t cap, size_t *n);
-/* DescriptorRepresentation (sift.cpp:1607-1631): fills descr_length and descriptor of each record */
+/* DescriptorRepresentation (sift.cpp:1607-1631): fills descr_length and descriptor of each record.
+ * Range: the histograms are 64-bit fixed-point sums that hold values below 2^14; pyramids the path makes itself
+ * (pixels 0..1, window radius <= 42) stay below 300.  For planes and scales handed in here the call checks that
+ * (largest - smallest pixel) * (largest window radius)^2 < 113000 and that every pixel is finite: SG_E_UNSUPPORTED /
+ * SG_E_INVALID otherwise (the reference, which sums in double, has no such limit). */
 int sg_descriptor_representation(sg_ctx *ctx, sg_keypoint *features, size_t n, const double *const *gauss,
                                  int width, int height, int octaves);
 /* std::sort(features, FeatureCmp) (sift.cpp:1640-1643,1703): ascending scale, ties keep input order */
@@ -208,6 +212,9 @@ int sg_last_octaves(const sg_ctx *ctx);
 int sg_level_dims(const sg_ctx *ctx, int octave, int *rows, int *cols);
 /* bit o set: levels 1 and 2 of octave o of the last call were produced by one launch (timed under SG_ST_BLUR_PAIR) */
 unsigned int sg_last_pair_octaves(const sg_ctx *ctx);
+/* device bytes this context has allocated as scratch of sg_match / sg_match_packed_device (0 until the first such
+ * call, grown on demand); sg_match_packed_device_noalloc never changes it */
+size_t sg_match_scratch_bytes(const sg_ctx *ctx);
 /* first octave of the last call whose levels all came from the one launch timed under SG_ST_PYR_TAIL (octaves small
  * enough for a workgroup's LDS); the octave count when there was no such launch */
 int sg_last_tail_octave(const sg_ctx *ctx);

@@ -44,7 +44,7 @@ EXPORTS = (
     "sg_downsample", "sg_gaussian_smooth", "sg_create_init_smooth_gray", "sg_gaussian_pyramid", "sg_sub",
     "sg_dog_pyramid", "sg_detect_local_extrema", "sg_calculate_scale", "sg_half_features",
     "sg_orientation_assignment", "sg_descriptor_representation", "sg_sort_features", "sg_last_octaves",
-    "sg_level_dims", "sg_last_pair_octaves", "sg_last_tail_octave", "sg_read_level", "sg_read_counters", "sg_read_work_counters", "sg_read_keypoints", "sg_read_features_unsorted",
+    "sg_level_dims", "sg_last_pair_octaves", "sg_match_scratch_bytes", "sg_last_tail_octave", "sg_read_level", "sg_read_counters", "sg_read_work_counters", "sg_read_keypoints", "sg_read_features_unsorted",
     "sg_set_profiling", "sg_get_stage_times", "sg_reset_stage_times", "sg_malloc", "sg_free", "sg_memcpy_h2d",
     "sg_memcpy_d2h", "sg_synth_vnoise5", "sg_match", "sg_match_packed_device",
     "sg_match_packed_device_noalloc", "sg_comm_unique_id", "sg_comm_create", "sg_comm_destroy",
@@ -137,6 +137,8 @@ def load_library():
     L.sg_last_octaves.argtypes = [vp]
     L.sg_last_pair_octaves.argtypes = [vp]
     L.sg_last_pair_octaves.restype = C.c_uint
+    L.sg_match_scratch_bytes.argtypes = [vp]
+    L.sg_match_scratch_bytes.restype = C.c_size_t
     L.sg_last_tail_octave.argtypes = [vp]
     L.sg_level_dims.argtypes = [vp, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.sg_read_level.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp]

@@ -1321,6 +1321,16 @@ int sg_extract(sg_ctx *c, const uint8_t *px, int width, int height, int channels
 int sg_last_octaves(const sg_ctx *c) { return c ? c->octaves : 0; }
 
 unsigned int sg_last_pair_octaves(const sg_ctx *c) { return c ? c->pair_octaves : 0; }
+
+size_t sg_match_scratch_bytes(const sg_ctx *c)
+{
+    if (!c)
+        return 0;
+    size_t bytes = c->mpart_bytes + (c->d_mbad ? sizeof(unsigned int) : 0);
+    for (int i = 0; i < 2; i++)
+        bytes += (size_t)c->m_cap[i] * (128 + sizeof(int));
+    return bytes;
+}
 int sg_last_tail_octave(const sg_ctx *c) { return c ? c->tail_octave : 0; }
 
 int sg_level_dims(const sg_ctx *c, int octave, int *rows, int *cols)
@@ -2322,6 +2332,35 @@ int sg_descriptor_representation(sg_ctx *c, sg_keypoint *features, size_t n, con
     int max_radius = 0;
     for (size_t i = 0; i < n; i++)
         max_radius = std::max(max_radius, descr_radius(features[i].octave_scale));
+    // The descriptor kernel adds into 64-bit fixed-point bins that hold values below 2^14 (kernels_describe.hip).  The
+    // path's own pyramids (pixel values 0..1, window radius at most 42) stay below 300; planes and scales handed in
+    // from outside are checked.  A bin's sum is bounded by (sum of a cell's bilinear weights over the sample grid,
+    // about shw^2 = (r / 3.54)^2, taken as 0.1 r^2) x (largest gradient magnitude, sqrt(2) x the pixel range); the
+    // planes must be finite.
+    if (n) {
+        Geometry g;
+        if (make_geometry(height, width, octaves, &g) != SG_OK)
+            return fail(c, SG_E_UNSUPPORTED, "too many octaves");
+        double vmin = 1.7976931348623157e308, vmax = -1.7976931348623157e308;
+        bool finite = true;
+        for (int o = 0; o < octaves; o++)
+            for (int l = 1; l <= 3; l++) { // the levels descriptors read (interval 1..3)
+                const double *pl = gauss[o * kLevels + l];
+                const size_t npx = (size_t)g.rows[o] * g.cols[o];
+                for (size_t i = 0; i < npx; i++) {
+                    const double v = pl[i];
+                    finite = finite && fabs(v) <= 1.7976931348623157e308; // false for NaN and infinities
+                    vmin = v < vmin ? v : vmin;
+                    vmax = v > vmax ? v : vmax;
+                }
+            }
+        if (!finite)
+            return fail(c, SG_E_INVALID, "the pyramid holds values that are not finite");
+        if (vmax > vmin && 0.1 * (double)max_radius * (double)max_radius * 1.4142135623730951 * (vmax - vmin) >= 16000.0)
+            return fail(c, SG_E_UNSUPPORTED,
+                        "pixel range times window area beyond what the descriptor histograms hold ((max - min pixel) * "
+                        "radius^2 must stay below 113000; the path's own pyramids have pixels 0..1 and radius <= 42)");
+    }
     invalidate_pending(c);
     descr_phase(c, pyr.tab, 1, max_radius);
     rc = finish(c);

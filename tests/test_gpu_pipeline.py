@@ -516,3 +516,31 @@ def test_fma_precision_mode_stays_within_tolerance(oracle):
         # the default mode beside it: bit-identical levels
         exact.extract(img)
         assert np.array_equal(exact.read_level(0, 5), ref.gauss[5])
+
+
+def test_descriptor_entry_point_checks_the_histogram_range(oracle, gpu64):
+    """DescriptorRepresentation on planes handed in from outside: the fixed-point histograms hold sums below 2^14, so
+    planes whose range times window area could exceed that, and planes with values that are not finite, are refused
+    (the path's own pyramids, pixels 0..1, are far inside); a large-scale feature on ordinary planes is taken."""
+    import sift_amd
+    from sift_amd import api
+    img = oracle.vnoise5(192, 144, 9)
+    dbg = oracle.Debug(img)
+    feats = dbg.features[:40].copy()
+    big = feats.copy()
+    big["octave_scale"] = 12.0  # radius 127: the widest window of the common kernel variant; pixels 0..1 are fine
+    out = gpu64.descriptor_representation(big, dbg.gauss, dbg.octaves)
+    assert out["descr_length"].min() == 128 and out["descriptor"].max() <= 255
+    scaled = [g * 1000.0 for g in dbg.gauss]  # range 1000 x radius^2 16129: beyond the histograms
+    with pytest.raises(sift_amd.SiftGpuError) as e:
+        gpu64.descriptor_representation(big, scaled, dbg.octaves)
+    assert e.value.status == api.SG_E_UNSUPPORTED
+    # the same planes with the features' own (small) windows are inside the range: taken, bins as for the plain planes
+    # (the descriptor is normalised, so a common factor of the pixels cancels)
+    small = gpu64.descriptor_representation(feats, [g * 16.0 for g in dbg.gauss], dbg.octaves)
+    assert np.array_equal(small["descriptor"], dbg.features[:40]["descriptor"])
+    bad = [g.copy() for g in dbg.gauss]
+    bad[1][3, 3] = np.nan
+    with pytest.raises(sift_amd.SiftGpuError) as e:
+        gpu64.descriptor_representation(feats, bad, dbg.octaves)
+    assert e.value.status == api.SG_E_INVALID

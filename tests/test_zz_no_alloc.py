@@ -68,3 +68,48 @@ def test_noalloc_matcher_equals_allocating_matcher():
         finally:
             for p, _ in sets:
                 ctx.free(p)
+
+
+def test_noalloc_matcher_allocates_nothing_on_a_fresh_context():
+    """The property the entry point exists for: on a context that has never run the allocating matcher (so that none
+    of its grow-on-demand buffers exists), the allocation-free matcher leaves the device's free memory unchanged --
+    outputs allocated beforehand, free memory read before and after -- and its result equals the allocating matcher's,
+    run afterwards."""
+    import ctypes as C
+    import sift_amd
+    cap = 8192
+    with sift_amd.SiftGPU(max_width=640, max_height=480) as ctx:
+        # hipMemGetInfo of the HIP runtime the library itself is linked to (a symbol lookup on the library's handle
+        # searches its dependencies; another copy of the runtime may be loaded in this process beside it)
+        mem_get_info = ctx.lib.hipMemGetInfo
+
+        def free_bytes():
+            free, total = C.c_size_t(0), C.c_size_t(0)
+            assert mem_get_info(C.byref(free), C.byref(total)) == 0
+            return free.value
+
+        sets = _packed_sets(ctx, [(640, 480, 21), (320, 240, 22)], cap)
+        (a, na), (b, nb) = sets
+        d_idx, d_dst = ctx.malloc(na * 4), ctx.malloc(na * 8)
+        try:
+            ctx.sync()
+            free_before = free_bytes()
+            assert ctx.lib.sg_match_scratch_bytes(ctx.ctx) == 0  # the allocating matcher has not run on this context
+            for _ in range(2):
+                ctx.match_packed_device_noalloc(a, na, b, nb, d_idx, d_dst, 0.8)
+                ctx.sync()
+            free_after = free_bytes()
+            assert free_after == free_before, (free_before, free_after)  # (the runtime's pool hides small requests)
+            assert ctx.lib.sg_match_scratch_bytes(ctx.ctx) == 0           # ... the context's own books do not
+            got_idx, got_dst = np.zeros(na, dtype=np.int32), np.zeros(2 * na, dtype=np.uint32)
+            ctx.d2h(got_idx, d_idx)
+            ctx.d2h(got_dst, d_dst)
+            # the allocating form on the same context allocates its scratch now (free memory drops) and agrees
+            want_idx, want_dst = _run(ctx, ctx.match_packed_device, a, na, b, nb)
+            assert ctx.lib.sg_match_scratch_bytes(ctx.ctx) >= (na + nb) * 132
+            assert np.array_equal(got_idx, want_idx) and np.array_equal(got_dst, want_dst)
+        finally:
+            ctx.free(d_idx)
+            ctx.free(d_dst)
+            for p, _ in sets:
+                ctx.free(p)

@@ -232,6 +232,15 @@ def packed_rows(buf, n):
     return np.sort(np.ascontiguousarray(a).view([("b", "V144")]).ravel())
 
 
+def multiset_common(a, b):
+    """Number of elements two arrays have in common, counted with multiplicity (the path keeps duplicate keypoints,
+    as the reference does, so a frame's feature list may hold the same record more than once)."""
+    ua, ca = np.unique(a, return_counts=True)
+    ub, cb = np.unique(b, return_counts=True)
+    _, ia, ib = np.intersect1d(ua, ub, assume_unique=True, return_indices=True)
+    return int(np.minimum(ca[ia], cb[ib]).sum())
+
+
 def fma_mode_agreement(sift_amd, torch, dev, dev_index, W, H, cap, frames, frame_bytes, first, B, out, counts):
     """The first frames of the last timed batch again with fused multiply-adds in the Gaussian filters (SG_F64_FMA),
     compared with what the timed run (the reference's separate multiplies and adds) produced for them: frames whose
@@ -251,10 +260,10 @@ def fma_mode_agreement(sift_amd, torch, dev, dev_index, W, H, cap, frames, frame
         same_count += int(len(a) == len(b))
         n_exact += len(a)
         n_fma += len(b)
-        identical += len(np.intersect1d(a, b))
-        ka = np.sort(np.frombuffer(a.tobytes(), np.uint8).reshape(-1, 144)[:, :16].copy().view([("k", "V16")]).ravel())
-        kb = np.sort(np.frombuffer(b.tobytes(), np.uint8).reshape(-1, 144)[:, :16].copy().view([("k", "V16")]).ravel())
-        same_keys += len(np.intersect1d(ka, kb))
+        identical += multiset_common(a, b)
+        ka = np.frombuffer(a.tobytes(), np.uint8).reshape(-1, 144)[:, :16].copy().view([("k", "V16")]).ravel()
+        kb = np.frombuffer(b.tobytes(), np.uint8).reshape(-1, 144)[:, :16].copy().view([("k", "V16")]).ravel()
+        same_keys += multiset_common(ka, kb)
     ctx.close()
     return {"frames": n, "frames_with_same_count": same_count, "features_exact": n_exact, "features_fma": n_fma,
             "features_identical_bytes": identical, "features_with_identical_position_scale_orientation": same_keys,

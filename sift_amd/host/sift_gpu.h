@@ -150,11 +150,17 @@ void SiftSetBatching(int max_batch);
 // depend on its pixels alone, so a batch shards by frame: GPU g of G takes frames [g * ceil(F/G), (g+1) * ceil(F/G)),
 // one host thread per GPU, no communication during extraction; then the GPUs all-gather their packed feature sets
 // (RCCL all-gather-v over xGMI: afterwards every GPU holds every frame's features, in frame order) and the host
-// receives them from GPU 0.  features[f] = the features of frames[f], ordered as Sift() orders them, in the packed
-// form of the throughput path: dx, dy, scale, ori as floats and the 128 descriptor values as bytes.
+// receives them from GPU 0, ordered per frame as Sift() orders them, in the packed form of the throughput path: dx,
+// dy, scale, ori as floats and the 128 descriptor values as bytes.
 struct SiftPackedFeature {
     float x, y, scale, ori;        // Keypoint.dx, .dy, .scale, .ori
     unsigned char descriptor[128]; // Keypoint.descriptor (integers 0..255)
+};
+struct SiftBatchFeatures {
+    std::vector<SiftPackedFeature> features; // all frames' features back to back, frame after frame
+    std::vector<size_t> first;               // frame f's features: features[first[f]] .. features[first[f + 1] - 1]
+    size_t count(size_t f) const { return first[f + 1] - first[f]; }
+    const SiftPackedFeature *frame(size_t f) const { return features.data() + first[f]; }
 };
 struct SiftMultiGpuOptions {
     int n_gpus = 0;                 // 0: every GPU of the node
@@ -166,6 +172,9 @@ struct SiftMultiGpuOptions {
                                     // memory instead of RCCL, which refuses two ranks on one GPU: for trying the
                                     // sharding on a machine with fewer GPUs than ranks
 };
-// Returns 0 (SG_OK) or a negative sg_status; *error (optional) receives the text.
-int SiftBatchMultiGpu(const std::vector<Mat> &frames, std::vector<std::vector<SiftPackedFeature>> &features,
+// Returns 0 (SG_OK) or a negative sg_status; *error (optional) receives the text.  One call runs at a time (others
+// wait); the GPUs' contexts, buffers and RCCL communicators are kept for the next call of the same shape until
+// SiftMultiGpuRelease() frees them.
+int SiftBatchMultiGpu(const std::vector<Mat> &frames, SiftBatchFeatures &result,
                       const SiftMultiGpuOptions &options = SiftMultiGpuOptions(), std::string *error = nullptr);
+void SiftMultiGpuRelease();

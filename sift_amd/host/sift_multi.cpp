@@ -57,6 +57,7 @@ struct Shared {
     SiftMultiGpuOptions opt;
     int ranks = 1, n_dev = 1, per = 0, w = 0, h = 0, ch = 0;
     unsigned char comm_id[SG_COMM_ID_BYTES];
+    bool pool_comm_ok = false; // every rank still holds a communicator of this many ranks: kept
     Barrier *barrier = nullptr;
     // what the ranks tell each other through host memory
     std::vector<int> status;            // per rank, of the phase just finished
@@ -66,21 +67,23 @@ struct Shared {
     std::vector<std::vector<uint32_t>> seen_counts; // per rank: all frames' counts as gathered on that rank
     std::vector<std::vector<SiftPackedFeature>> seen_last; // per rank: last feature of every frame as gathered there
     std::vector<std::vector<SiftPackedFeature>> rehearsal_feats; // rehearsal: every rank's compacted shard
-    std::vector<std::vector<SiftPackedFeature>> *out = nullptr;
+    SiftBatchFeatures *out = nullptr;
 };
 
+// What a rank holds on its GPU.  Kept between calls in a pool (creating a context of 32 frames, its streams and events,
+// and an RCCL communicator costs far more than extracting a small batch), keyed by rank; a call whose shape differs
+// (frame size, batch, capacity, parameters, number of ranks) rebuilds what depends on it.
 struct Rank {
     sg_ctx *ctx = nullptr, *up = nullptr;
     void *comm = nullptr;
     void *d_img[2] = {nullptr, nullptr}, *d_out = nullptr, *d_cnt = nullptr, *d_all = nullptr, *d_all_cnt = nullptr;
     void *pinned[2] = {nullptr, nullptr};
-    ~Rank()
+    // shape of what is held
+    int device = -1, comm_ranks = 0, w = 0, h = 0, ch = 0, bsz = 0, per = 0, nointerval = -1, all_cnt_ranks = 0;
+    double sigma = 0;
+    size_t cap = 0, all_cap = 0, pinned_bytes = 0;
+    void free_shard()
     {
-        if (comm)
-            sg_comm_destroy(comm);
-        for (void *p : pinned)
-            if (p)
-                sg_host_free(p);
         if (ctx) {
             void *bufs[] = {d_img[0], d_img[1], d_out, d_cnt, d_all, d_all_cnt};
             for (void *b : bufs)
@@ -88,10 +91,45 @@ struct Rank {
                     sg_free(ctx, b);
             sg_destroy(ctx);
         }
+        ctx = nullptr;
+        d_img[0] = d_img[1] = d_out = d_cnt = d_all = d_all_cnt = nullptr;
+        all_cap = 0;
+        all_cnt_ranks = 0;
+        cap = 0;
+    }
+    ~Rank()
+    {
+        if (comm)
+            sg_comm_destroy(comm);
+        for (void *p : pinned)
+            if (p)
+                sg_host_free(p);
+        free_shard();
         if (up)
             sg_destroy(up);
     }
 };
+
+std::mutex g_call_mutex;          // one SiftBatchMultiGpu call at a time
+std::vector<Rank *> g_pool;       // by rank; touched under g_call_mutex (each rank thread takes its own entry)
+
+void SiftMultiGpuRelease_locked()
+{
+    for (Rank *r : g_pool)
+        delete r;
+    g_pool.clear();
+}
+
+// true when every rank of a call of `ranks` ranks still holds its communicator of that size
+bool pool_has_comm(int ranks)
+{
+    if ((int)g_pool.size() < ranks)
+        return false;
+    for (int g = 0; g < ranks; g++)
+        if (!g_pool[(size_t)g] || !g_pool[(size_t)g]->comm || g_pool[(size_t)g]->comm_ranks != ranks)
+            return false;
+    return true;
+}
 
 // The ranks meet and learn whether all of them are well: true on every rank or on none.  (Two meetings: nobody writes
 // its next status before everybody has read this one.)
@@ -114,29 +152,49 @@ void rank_main(Shared &s, int rank)
             e += std::string(": ") + sg_last_error(c);
         s.error[(size_t)rank] = e;
     };
-    Rank r;
     const int F = (int)s.frames->size();
     const int first = std::min(F, rank * s.per), stop = std::min(F, first + s.per), mine = stop - first;
     const int device = s.opt.rehearsal ? rank % s.n_dev : rank;
     const int bsz = std::max(1, std::min(s.opt.batch, s.per));
     const size_t frame_bytes = (size_t)s.w * s.h * s.ch;
+    const bool rccl = s.ranks > 1 && !s.opt.rehearsal;
     size_t cap = s.opt.max_features_per_frame ? (size_t)s.opt.max_features_per_frame : (size_t)s.w * s.h / 40 + 4096;
 
-    // ---- set-up: contexts, communicator (all ranks enter ncclCommInitRank together), buffers ----
+    // ---- set-up: what the pool holds for this rank is kept where its shape fits ----
+    Rank *&slot = g_pool[(size_t)rank];
+    if (slot && slot->device != device) {
+        delete slot;
+        slot = nullptr;
+    }
+    if (!slot)
+        slot = new Rank;
+    Rank &r = *slot;
+    r.device = device;
     sg_params p;
-    sg_default_params(&p);
-    p.device = device;
-    p.max_width = 64;
-    p.max_height = 64;
-    int rc = sg_create(&p, &r.up);
-    if (rc != SG_OK)
-        fail(rc, "sg_create (upload context)", nullptr);
+    int rc = SG_OK;
+    if (!r.up) {
+        sg_default_params(&p);
+        p.device = device;
+        p.max_width = 64;
+        p.max_height = 64;
+        rc = sg_create(&p, &r.up);
+        if (rc != SG_OK)
+            fail(rc, "sg_create (upload context)", nullptr);
+    }
+    const bool keep_comm = s.pool_comm_ok; // decided once for all ranks, before the threads started
+    if (r.comm && !(rccl && keep_comm)) {
+        sg_comm_destroy(r.comm);
+        r.comm = nullptr;
+        r.comm_ranks = 0;
+    }
     if (!all_ok(s))
         return;
-    if (s.ranks > 1 && !s.opt.rehearsal) {
+    if (rccl && !r.comm) { // all ranks enter ncclCommInitRank together
         rc = sg_comm_create(r.up, s.comm_id, rank, s.ranks, &r.comm);
         if (rc != SG_OK)
             fail(rc, "sg_comm_create", r.up);
+        else
+            r.comm_ranks = s.ranks;
     }
     if (!all_ok(s))
         return;
@@ -144,37 +202,55 @@ void rank_main(Shared &s, int rank)
     // ---- extraction of the shard; every rank repeats it with a larger per-frame capacity if any rank overflowed ----
     for (int attempt = 0; attempt < 4; attempt++) {
         s.need[(size_t)rank] = 0;
-        if (r.ctx) { // a new capacity: everything sized from it goes
-            void *bufs[] = {r.d_img[0], r.d_img[1], r.d_out, r.d_cnt};
-            for (void *b : bufs)
-                if (b)
-                    sg_free(r.ctx, b);
-            r.d_img[0] = r.d_img[1] = r.d_out = r.d_cnt = nullptr;
-            sg_destroy(r.ctx);
-            r.ctx = nullptr;
-        }
-        sg_default_params(&p);
-        p.device = device;
-        p.sigma = s.opt.sigma;
-        p.nointerval = s.opt.nointerval ? 1 : 0;
-        p.max_width = s.w;
-        p.max_height = s.h;
-        p.max_batch = bsz;
-        p.max_features = (int)std::min<size_t>(cap, 0x7fffffff);
-        rc = sg_create(&p, &r.ctx);
-        if (rc != SG_OK) {
-            fail(rc, "sg_create", nullptr);
-        } else {
-            rc = sg_malloc(r.ctx, (size_t)s.per * cap * sizeof(sg_packed_feature), &r.d_out);
-            if (rc == SG_OK)
-                rc = sg_malloc(r.ctx, sizeof(uint32_t) * (size_t)s.per, &r.d_cnt);
-            for (int b = 0; b < 2 && rc == SG_OK; b++) {
-                rc = sg_malloc(r.ctx, frame_bytes * (size_t)bsz, &r.d_img[b]);
-                if (rc == SG_OK && !r.pinned[b])
-                    rc = sg_host_alloc(frame_bytes * (size_t)bsz, &r.pinned[b]);
+        const int ni = s.opt.nointerval ? 1 : 0;
+        const bool fits = r.ctx && r.w == s.w && r.h == s.h && r.ch == s.ch && r.bsz == bsz && r.per == s.per &&
+                          r.cap == cap && r.sigma == s.opt.sigma && r.nointerval == ni;
+        if (!fits) { // another shape (or a larger capacity after an overflow): everything sized from it goes
+            r.free_shard();
+            sg_default_params(&p);
+            p.device = device;
+            p.sigma = s.opt.sigma;
+            p.nointerval = ni;
+            p.max_width = s.w;
+            p.max_height = s.h;
+            p.max_batch = bsz;
+            p.max_features = (int)std::min<size_t>(cap, 0x7fffffff);
+            rc = sg_create(&p, &r.ctx);
+            if (rc != SG_OK) {
+                r.ctx = nullptr;
+                fail(rc, "sg_create", nullptr);
+            } else {
+                rc = sg_malloc(r.ctx, (size_t)s.per * cap * sizeof(sg_packed_feature), &r.d_out);
+                if (rc == SG_OK)
+                    rc = sg_malloc(r.ctx, sizeof(uint32_t) * (size_t)s.per, &r.d_cnt);
+                for (int b = 0; b < 2 && rc == SG_OK; b++)
+                    rc = sg_malloc(r.ctx, frame_bytes * (size_t)bsz, &r.d_img[b]);
+                if (rc == SG_OK && r.pinned_bytes < frame_bytes * (size_t)bsz) {
+                    for (int b = 0; b < 2; b++) {
+                        if (r.pinned[b])
+                            sg_host_free(r.pinned[b]);
+                        r.pinned[b] = nullptr;
+                    }
+                    r.pinned_bytes = 0;
+                    for (int b = 0; b < 2 && rc == SG_OK; b++)
+                        rc = sg_host_alloc(frame_bytes * (size_t)bsz, &r.pinned[b]);
+                    if (rc == SG_OK)
+                        r.pinned_bytes = frame_bytes * (size_t)bsz;
+                }
+                if (rc != SG_OK) {
+                    fail(rc, "device or page-locked memory for the shard", r.ctx);
+                    r.free_shard();
+                } else {
+                    r.w = s.w;
+                    r.h = s.h;
+                    r.ch = s.ch;
+                    r.bsz = bsz;
+                    r.per = s.per;
+                    r.cap = cap;
+                    r.sigma = s.opt.sigma;
+                    r.nointerval = ni;
+                }
             }
-            if (rc != SG_OK)
-                fail(rc, "device or page-locked memory for the shard", r.ctx);
         }
         if (s.status[(size_t)rank] == SG_OK) {
             // frames this rank does not have (the last shard may be short) count zero features
@@ -244,20 +320,35 @@ void rank_main(Shared &s, int rank)
     size_t total = 0;
     for (size_t v : s.total)
         total += v;
-    const bool rccl = s.ranks > 1 && !s.opt.rehearsal;
     const size_t gather_total = s.opt.rehearsal ? my_total : total; // without a communicator a rank gathers itself
     const int gather_ranks = rccl ? s.ranks : 1;
-    rc = sg_malloc(r.ctx, std::max<size_t>(gather_total, 1) * sizeof(sg_packed_feature), &r.d_all);
-    if (rc == SG_OK)
+    if (r.all_cap < std::max<size_t>(gather_total, 1)) {
+        if (r.d_all)
+            sg_free(r.ctx, r.d_all);
+        r.d_all = nullptr;
+        r.all_cap = 0;
+        const size_t want = std::max<size_t>(gather_total + gather_total / 8, 1);
+        rc = sg_malloc(r.ctx, want * sizeof(sg_packed_feature), &r.d_all);
+        if (rc == SG_OK)
+            r.all_cap = want;
+    }
+    if (rc == SG_OK && r.all_cnt_ranks < gather_ranks) {
+        if (r.d_all_cnt)
+            sg_free(r.ctx, r.d_all_cnt);
+        r.d_all_cnt = nullptr;
+        r.all_cnt_ranks = 0;
         rc = sg_malloc(r.ctx, sizeof(uint32_t) * (size_t)s.per * (size_t)gather_ranks, &r.d_all_cnt);
+        if (rc == SG_OK)
+            r.all_cnt_ranks = gather_ranks;
+    }
     std::vector<size_t> rank_first((size_t)gather_ranks + 1, 0);
     if (rc != SG_OK)
         fail(rc, "device memory for the gathered features", r.ctx);
     if (!all_ok(s)) // no rank enters the collective unless every rank can
         return;
-    rc = sg_allgather_features(r.ctx, r.comm, static_cast<const sg_packed_feature *>(r.d_out),
+    rc = sg_allgather_features(r.ctx, rccl ? r.comm : nullptr, static_cast<const sg_packed_feature *>(r.d_out),
                                static_cast<const uint32_t *>(r.d_cnt), s.per, cap, static_cast<sg_packed_feature *>(r.d_all),
-                               std::max<size_t>(gather_total, 1), static_cast<uint32_t *>(r.d_all_cnt), rank_first.data());
+                               r.all_cap, static_cast<uint32_t *>(r.d_all_cnt), rank_first.data());
     if (rc == SG_OK)
         rc = sg_sync(r.ctx);
     if (rc != SG_OK)
@@ -285,21 +376,23 @@ void rank_main(Shared &s, int rank)
     rc = sg_memcpy_d2h(r.ctx, cnts.data(), r.d_all_cnt, sizeof(uint32_t) * cnts.size());
     std::vector<SiftPackedFeature> &last = s.seen_last[(size_t)rank];
     last.assign(cnts.size(), SiftPackedFeature());
-    if (rank == 0) { // rank 0 brings the whole set down; the others sample it
-        std::vector<SiftPackedFeature> all(total);
+    if (rank == 0) { // rank 0 brings the whole set down, straight into the caller's array; the others sample it
+        std::vector<SiftPackedFeature> &all = s.out->features;
+        all.resize(total);
         if (rc == SG_OK && total)
             rc = sg_memcpy_d2h(r.ctx, all.data(), r.d_all, total * sizeof(SiftPackedFeature));
         if (rc == SG_OK) {
-            s.out->assign((size_t)F, std::vector<SiftPackedFeature>());
+            s.out->first.assign((size_t)F + 1, 0);
             size_t at = 0;
             for (size_t f = 0; f < cnts.size(); f++) {
                 const size_t n = std::min<size_t>(cnts[f], cap);
                 if (f < (size_t)F)
-                    (*s.out)[f].assign(all.begin() + (ptrdiff_t)at, all.begin() + (ptrdiff_t)(at + n));
+                    s.out->first[f] = at;
                 if (n)
                     last[f] = all[at + n - 1];
                 at += n;
             }
+            s.out->first[(size_t)F] = at; // frames beyond F are the padding of the last shard: no features
         }
     } else {
         size_t at = 0;
@@ -318,15 +411,18 @@ void rank_main(Shared &s, int rank)
 
 } // namespace
 
-int SiftBatchMultiGpu(const std::vector<Mat> &frames, std::vector<std::vector<SiftPackedFeature>> &features,
-                      const SiftMultiGpuOptions &options, std::string *error)
+int SiftBatchMultiGpu(const std::vector<Mat> &frames, SiftBatchFeatures &result, const SiftMultiGpuOptions &options,
+                      std::string *error)
 {
     auto bad = [&](int rc, const std::string &what) {
         if (error)
             *error = what;
+        result.features.clear();
+        result.first.assign(frames.size() + 1, 0);
         return rc;
     };
-    features.clear();
+    result.features.clear();
+    result.first.assign(frames.size() + 1, 0);
     if (frames.empty())
         return SG_OK;
     Shared s;
@@ -348,11 +444,6 @@ int SiftBatchMultiGpu(const std::vector<Mat> &frames, std::vector<std::vector<Si
     if (!(options.sigma > 1.0))
         return bad(SG_E_INVALID, "sigma must exceed 1");
     s.per = ((int)frames.size() + s.ranks - 1) / s.ranks;
-    if (s.ranks > 1 && !options.rehearsal) {
-        const int rc = sg_comm_unique_id(s.comm_id);
-        if (rc != SG_OK)
-            return bad(rc, "sg_comm_unique_id: RCCL is not usable");
-    }
     Barrier barrier(s.ranks);
     s.barrier = &barrier;
     s.status.assign((size_t)s.ranks, SG_OK);
@@ -362,7 +453,18 @@ int SiftBatchMultiGpu(const std::vector<Mat> &frames, std::vector<std::vector<Si
     s.seen_counts.resize((size_t)s.ranks);
     s.seen_last.resize((size_t)s.ranks);
     s.rehearsal_feats.resize((size_t)s.ranks);
-    s.out = &features;
+    s.out = &result;
+    // One call at a time: the ranks' contexts, buffers and communicators are kept between calls (SiftMultiGpuRelease
+    // frees them) and belong to the call that runs.
+    std::lock_guard<std::mutex> one_call(g_call_mutex);
+    if (g_pool.size() < (size_t)s.ranks)
+        g_pool.resize((size_t)s.ranks, nullptr);
+    s.pool_comm_ok = pool_has_comm(s.ranks);
+    if (s.ranks > 1 && !options.rehearsal && !s.pool_comm_ok) {
+        const int rc = sg_comm_unique_id(s.comm_id);
+        if (rc != SG_OK)
+            return bad(rc, "sg_comm_unique_id: RCCL is not usable");
+    }
     std::vector<std::thread> threads;
     for (int g = 1; g < s.ranks; g++)
         threads.emplace_back(rank_main, std::ref(s), g);
@@ -371,21 +473,24 @@ int SiftBatchMultiGpu(const std::vector<Mat> &frames, std::vector<std::vector<Si
         t.join();
     for (int g = 0; g < s.ranks; g++)
         if (s.status[(size_t)g] != SG_OK) {
-            features.clear();
+            SiftMultiGpuRelease_locked(); // whatever state the ranks were left in is not used again
             return bad(s.status[(size_t)g], "GPU " + std::to_string(g) + ": " + s.error[(size_t)g]);
         }
     if (options.rehearsal) {
-        features.assign(frames.size(), std::vector<SiftPackedFeature>());
+        result.features.clear();
         for (int g = 0; g < s.ranks; g++) {
             size_t at = 0;
             for (int i = 0; i < s.per; i++) {
                 const size_t f = (size_t)g * (size_t)s.per + (size_t)i, n = s.seen_counts[(size_t)g][(size_t)i];
-                if (f < frames.size())
-                    features[f].assign(s.rehearsal_feats[(size_t)g].begin() + (ptrdiff_t)at,
-                                       s.rehearsal_feats[(size_t)g].begin() + (ptrdiff_t)(at + n));
+                if (f < frames.size()) {
+                    result.first[f] = result.features.size();
+                    result.features.insert(result.features.end(), s.rehearsal_feats[(size_t)g].begin() + (ptrdiff_t)at,
+                                           s.rehearsal_feats[(size_t)g].begin() + (ptrdiff_t)(at + n));
+                }
                 at += n;
             }
         }
+        result.first[frames.size()] = result.features.size();
         return SG_OK;
     }
     // every GPU must hold the same gathered set: the counts and the sampled features of all ranks agree with rank 0's
@@ -393,10 +498,14 @@ int SiftBatchMultiGpu(const std::vector<Mat> &frames, std::vector<std::vector<Si
         const bool same = s.seen_counts[(size_t)g] == s.seen_counts[0] &&
                           std::memcmp(s.seen_last[(size_t)g].data(), s.seen_last[0].data(),
                                       s.seen_last[0].size() * sizeof(SiftPackedFeature)) == 0;
-        if (!same) {
-            features.clear();
+        if (!same)
             return bad(SG_E_HIP, "GPU " + std::to_string(g) + " holds a different gathered set than GPU 0");
-        }
     }
     return SG_OK;
+}
+
+void SiftMultiGpuRelease()
+{
+    std::lock_guard<std::mutex> one_call(g_call_mutex);
+    SiftMultiGpuRelease_locked();
 }

@@ -457,7 +457,7 @@ def main():
         cap_all = world * B * cap
         g_outs = [torch.empty(cap_all * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         g_cnts = [torch.zeros(world * B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-        if world == 1 or dist.get_backend() == "nccl":
+        if (world == 1 or dist.get_backend() == "nccl") and os.environ.get("SIFT_BENCH_EXCHANGE", "abi") != "torch":
             # Every rank first checks on its own that the library can bind RCCL, and the ranks agree on the outcome
             # before any of them enters the collective set-up: a rank that cannot must not leave the others waiting.
             why = ""
@@ -494,6 +494,8 @@ def main():
                     raise RuntimeError("the exchange step needs RCCL through the C ABI: " + why)
                 exchange = ("torch.distributed all-gather-v over %s (RCCL through the C ABI was not usable on every "
                             "rank%s)" % (dist.get_backend(), ": " + why if why else ""))
+        elif world > 1 and dist.get_backend() == "nccl":
+            exchange = "torch.distributed all-gather-v over nccl (SIFT_BENCH_EXCHANGE=torch)"
         else:
             exchange = "torch.distributed all-gather-v (%s rehearsal)" % dist.get_backend()
     gathered_total = [0] * nbuf   # features in the gathered buffer b
@@ -555,9 +557,27 @@ def main():
             dist.barrier()
 
     # ---- warmup ----
-    for s in range(WU):
+    # With several ranks the first all-gather through the C ABI's own RCCL binding happens here.  Should it never
+    # return (a communicator that cannot form, say), the run ends with a message instead of sitting until the caller's
+    # time limit: SIFT_BENCH_EXCHANGE=torch then takes the same exchange through torch.distributed instead.
+    watchdog = None
+    if world > 1 and xctx is not None:
+        import threading
+
+        def stuck():
+            sys.stderr.write("bench.py rank %d: the warm-up exchange (sg_allgather_features over RCCL) did not finish in "
+                             "300 s; rerun with SIFT_BENCH_EXCHANGE=torch to exchange through torch.distributed\n" % rank)
+            sys.stderr.flush()
+            os._exit(4)
+
+        watchdog = threading.Timer(300.0, stuck)
+        watchdog.daemon = True
+        watchdog.start()
+    for s in range(max(WU, 1 if world > 1 else 0)):
         submit(s)
     drain()
+    if watchdog is not None:
+        watchdog.cancel()
     for c in ctxs:
         if not args.no_profile:
             c.set_profiling(True)

@@ -457,7 +457,7 @@ def main():
         cap_all = world * B * cap
         g_outs = [torch.empty(cap_all * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         g_cnts = [torch.zeros(world * B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-        if (world == 1 or dist.get_backend() == "nccl") and os.environ.get("SIFT_BENCH_EXCHANGE", "abi") != "torch":
+        if world == 1 or (dist.get_backend() == "nccl" and os.environ.get("SIFT_BENCH_EXCHANGE", "abi") != "torch"):
             # Every rank first checks on its own that the library can bind RCCL, and the ranks agree on the outcome
             # before any of them enters the collective set-up: a rank that cannot must not leave the others waiting.
             why = ""

@@ -60,12 +60,15 @@ def octave_dims(w, h):
 
 
 def measured_stream_ceilings():
-    """What plain streams reach on this part (profiles/ubench/stream_ceilings.hip, output committed under
-    profiles/r*/stream_ceilings.txt): read-only, write-only and one-read-one-write rates in GB/s, the yardsticks the
-    pyramid kernels' rates are read against beside the nominal 8 TB/s."""
+    """What plain streams reach on this part, from the committed outputs of the micro-benchmarks under
+    profiles/ubench/ (GB/s): read-only, write-only and one-read-one-write rates of persistent loops
+    (stream_ceilings.hip), the copy whose workgroups take one 4 KB piece each and end -- the shape that reaches the
+    part's 6.3 TB/s -- and the best persistent copy (copy_ceiling.hip), and the strip walk of the blur kernels at
+    segment lengths a column filter can use (stream_ceilings.hip with short segments).  The yardsticks the pyramid
+    kernels' rates are read against beside the nominal 8 TB/s."""
     import glob
+    out = {}
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "stream_ceilings.txt")), reverse=True):
-        out = {}
         try:
             for line in open(path):
                 m = re.match(r"(linear copy|read only|write only)\s+[\d.]+ ms\s+([\d.]+) TB/s", line)
@@ -75,8 +78,40 @@ def measured_stream_ceilings():
             continue
         if out:
             out["source"] = os.path.relpath(path, ROOT)
-            return out
-    return None
+            break
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "copy_ceiling_8g.txt")), reverse=True):
+        try:
+            one_trip, persistent = 0.0, 0.0
+            for line in open(path):
+                m = re.match(r"(.+?)\s+avg [\d.]+ ms ([\d.]+) TB/s", line)
+                if not m:
+                    continue
+                rate = float(m.group(2)) * 1e3
+                if m.group(1).startswith("one trip per thread U1 "):
+                    one_trip = rate
+                elif m.group(1).startswith(("grid-stride", "chunk")):
+                    persistent = max(persistent, rate)
+            if one_trip:
+                out["copy_one_4KB_piece_per_workgroup"] = one_trip
+                out["copy_persistent_loops_best"] = persistent
+                out["copy_source"] = os.path.relpath(path, ROOT)
+                break
+        except OSError:
+            continue
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "strip_short.txt")), reverse=True):
+        try:
+            best = 0.0
+            for line in open(path):
+                m = re.match(r"NW\d+ V\d+ PF\d+ nt\d remap0 seg (\d+)\s+[\d.]+ ms\s+([\d.]+) TB/s", line)
+                if m and int(m.group(1)) >= 32:
+                    best = max(best, float(m.group(2)) * 1e3)
+            if best:
+                out["strip_walk_segments_of_32_rows_and_more_best"] = best
+                out["strip_source"] = os.path.relpath(path, ROOT)
+                break
+        except OSError:
+            continue
+    return out or None
 
 
 def measured_traffic(kernel, tname, batch, width, height):

@@ -135,7 +135,11 @@ def measured_traffic(kernel, tname, batch, width, height):
             if d and name.startswith("sg::detect_k<%s," % d.group(1)):
                 return rec["hbm_bytes_per_launch"]
             if m and name.startswith("sg::%s<%s, %s," % (m.group(1), m.group(2), m.group(3))):
-                if m.group(1) != "blur_win_k" or name.endswith("true>") == bool(m.group(4)):  # true> = upsampling form
+                targs = [a.strip() for a in name[name.index("<") + 1: name.rindex(">")].split(",")]
+                if targs[-1] == "true":  # the fused multiply-add instantiation: another mode's launches
+                    continue
+                # blur_win_k<T, R, V, UPS, GDMA, F>: the fourth argument marks the upsampling form
+                if m.group(1) != "blur_win_k" or (len(targs) > 3 and targs[3] == "true") == bool(m.group(4)):
                     return rec["hbm_bytes_per_launch"]
     return None
 

@@ -470,7 +470,10 @@ constexpr int win_waves_per_simd(int R) { return R <= 6 ? SG_WIN_WPE6 : (R <= 8 
 
 // Input rows per iteration: more rows per iteration mean fewer window moves per row (2R per iteration) and fewer LDS
 // hand-offs; worth its registers only at the widest radius, whose kernel runs at two waves per SIMD anyway.
-constexpr int win_rows_per_iter(int R) { return R > 10 ? 4 : 2; }
+#ifndef SG_WIN_KR13
+#define SG_WIN_KR13 4
+#endif
+constexpr int win_rows_per_iter(int R) { return R > 10 ? SG_WIN_KR13 : 2; }
 
 // Gray rows of the upsampling form staged by direct-to-LDS loads (GDMA): geometry of a wave's ring.
 template <typename T, int R, int V>

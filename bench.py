@@ -688,16 +688,23 @@ def main():
         counts_ok = torch.equal(want_cnt.cpu().to(torch.int64), g_cnt.reshape(-1).cpu().to(torch.int64))
         # (3) checksum over all ranks' features
         words = g_feat[: total * 144].view(torch.int64)
-        weights = torch.arange(words.numel(), dtype=torch.int64, device=words.device) * 2654435761 + 1
-        cs = int((words * weights).sum().item()) if total else 0
-        cs_t = torch.tensor([cs, -cs, 1 if (own_ok and counts_ok) else 0], dtype=torch.int64,
-                            device=dev if on_dev else "cpu")
+        cs, piece = 0, 1 << 24  # in pieces: the gathered set of eight ranks is gigabytes
+        for w0 in range(0, words.numel(), piece):
+            w = words[w0: w0 + piece]
+            weights = (torch.arange(w.numel(), dtype=torch.int64, device=w.device) + w0) * 2654435761 + 1
+            cs = (cs + int((w * weights).sum().item())) & 0xffffffffffffffff
+        if cs >= 1 << 63:
+            cs -= 1 << 64  # as a signed 64-bit value, so that it travels in an int64 tensor
+        where = dev if on_dev else "cpu"
+        lo = torch.tensor([cs, 1 if (own_ok and counts_ok) else 0], dtype=torch.int64, device=where)
+        hi = torch.tensor([cs], dtype=torch.int64, device=where)
         if world > 1:
-            dist.all_reduce(cs_t, op=dist.ReduceOp.MIN)
-        checksum_equal = int(cs_t[0].item()) == -int(cs_t[1].item())
-        exchange_check = {"ok": bool(cs_t[2].item()) and checksum_equal, "ranks": world, "features_gathered": total,
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        checksum_equal = int(lo[0].item()) == int(hi[0].item())  # smallest = largest: the same on every rank
+        exchange_check = {"ok": bool(lo[1].item()) and checksum_equal, "ranks": world, "features_gathered": total,
                           "own_slot_equal": bool(own_ok), "counts_equal": bool(counts_ok),
-                          "all_ranks_own_slot_and_counts_ok": bool(cs_t[2].item()), "checksum_equal": checksum_equal,
+                          "all_ranks_own_slot_and_counts_ok": bool(lo[1].item()), "checksum_equal": checksum_equal,
                           "checksum": "%016x" % (cs & 0xffffffffffffffff)}
         del tmp
     for c in ctxs:

@@ -769,6 +769,7 @@ static int ensure_out(sg_ctx *c, size_t bytes)
 // moving them as bytes cuts the transfer five-fold, and the caller's memory, usually pageable, is written once, by
 // the CPU.)  Synchronises the stream.
 constexpr size_t kStagePiece = 4u << 20;
+constexpr size_t kUploadPiece = 1u << 20; // pieces in which a pageable image goes through the page-locked buffer
 constexpr size_t kStageRecs = kStagePiece / sizeof(WireRec);
 
 static int ensure_stage(sg_ctx *c)
@@ -1168,9 +1169,13 @@ int sg_extract_begin(sg_ctx *c, const uint8_t *px, int width, int height, int ch
         // which serialises host threads that each drive a context).
         const size_t nbytes = image_bytes(width, height, channels, stride);
         const bool pinned = ensure_pinned_in(c, nbytes) == SG_OK;
-        if (pinned)
-            memcpy(c->h_in, px, nbytes);
-        HIPCHK(c, hipMemcpyAsync(c->d_in, pinned ? c->h_in : px, nbytes, hipMemcpyHostToDevice, c->stream));
+        if (!pinned)
+            HIPCHK(c, hipMemcpyAsync(c->d_in, px, nbytes, hipMemcpyHostToDevice, c->stream));
+        for (size_t at = 0; pinned && at < nbytes; at += kUploadPiece) { // a piece is on the bus while the next is copied
+            const size_t len = std::min(kUploadPiece, nbytes - at);
+            memcpy(c->h_in + at, px + at, len);
+            HIPCHK(c, hipMemcpyAsync(c->d_in + at, c->h_in + at, len, hipMemcpyHostToDevice, c->stream));
+        }
     }
     rc = run_pipeline(c, c->d_in, 1, width, height, channels, stride, img_bytes);
     if (rc != SG_OK)
@@ -1227,12 +1232,17 @@ int sg_extract_batch_begin(sg_ctx *c, const uint8_t *const *imgs, int n_img, int
         return rc;
     const bool staged = !pinned && ensure_pinned_in(c, img_bytes * n_img) == SG_OK;
     for (int i = 0; i < n_img; i++) {
-        const uint8_t *src = imgs[i];
-        if (staged) {
-            memcpy(c->h_in + img_bytes * i, imgs[i], nbytes);
-            src = c->h_in + img_bytes * i;
+        if (!staged) {
+            HIPCHK(c, hipMemcpyAsync(c->d_in + img_bytes * i, imgs[i], nbytes, hipMemcpyHostToDevice, c->stream));
+            continue;
         }
-        HIPCHK(c, hipMemcpyAsync(c->d_in + img_bytes * i, src, nbytes, hipMemcpyHostToDevice, c->stream));
+        // through the page-locked buffer a piece at a time: the transfer of one piece runs while the next is copied
+        for (size_t at = 0; at < nbytes; at += kUploadPiece) {
+            const size_t len = std::min(kUploadPiece, nbytes - at);
+            memcpy(c->h_in + img_bytes * i + at, imgs[i] + at, len);
+            HIPCHK(c, hipMemcpyAsync(c->d_in + img_bytes * i + at, c->h_in + img_bytes * i + at, len,
+                                     hipMemcpyHostToDevice, c->stream));
+        }
     }
     rc = run_pipeline(c, c->d_in, n_img, width, height, channels, stride, img_bytes);
     if (rc != SG_OK)

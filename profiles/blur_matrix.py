@@ -38,7 +38,9 @@ def main():
                      st.get("blur_col2", 0), st.get("blur_col3", 0), st.get("blur_col4", 0), st.get("blur_col5", 0),
                      st.get("detect", 0), rf["all_blur_launches_GBps"] or 0,
                      " ".join("%s=%.0f" % (k.replace("blur_", ""), v["GBps"]) for k, v in bk.items()) +
-                     " det=%.0f" % r["detect_kernel"]["GBps"]))
+                     " det=%.0f" % r["detect_kernel"]["GBps"] +
+                     " | refine %.2f orient %.2f descr %.2f sort %.2f ms" % (st.get("refine", 0), st.get("orient", 0),
+                                                                             st.get("descr", 0), st.get("sort", 0))))
         print(line, flush=True)
         out.write(line + "\n")
         out.flush()

@@ -51,6 +51,60 @@ __device__ __forceinline__ void lds_add_fixed(unsigned long long *p, double a, d
     __hip_atomic_fetch_add(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// LDS addresses as 32-bit integers (what the ds_ instructions take), for address arithmetic the compiler is not to
+// rearrange: a * b + c with 24-bit factors is one full-rate instruction.
+typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
+__device__ __forceinline__ unsigned int lds_address(void *p)
+{
+    return (unsigned int)(size_t)(__attribute__((address_space(3))) void *)p;
+}
+__device__ __forceinline__ unsigned int mad_u24(unsigned int a, unsigned int b_uniform, unsigned int c)
+{
+    unsigned int d;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+}
+__device__ __forceinline__ void lds_add_fixed_at(unsigned int address, double a, double b)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(a * b);
+#ifdef SG_X_NOATOM // timing experiment: the product is formed, the add is not issued
+    asm volatile("" ::"v"(bits), "v"(address));
+#else
+    __hip_atomic_fetch_add((lds_u64_t *)(size_t)address, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+
+// Two histogram adds (the two orientation bins of one cell) for the lanes of `mask`, which is a wave mask in scalar
+// registers, computed well before: the execution mask is set from it around the two adds and put back.  Setting the
+// execution mask from scalar registers costs nothing, whereas a vector compare whose result goes straight into the
+// execution mask, with vector work behind it -- what an `if` around the adds compiles to -- holds up the whole SIMD,
+// other waves included, for about the time of three double-precision instructions (measured: 6.7 ns against
+// 2.2 ns per v_fma_f64 at five waves per SIMD).  The products are formed for every lane.
+template <int OFFSET>
+__device__ __forceinline__ void lds_add_fixed_pair_masked(unsigned int address, double a, double b0, double b1,
+                                                          unsigned long long mask)
+{
+    const double p0 = a * b0, p1 = a * b1; // bit patterns = whole units (see lds_add_fixed)
+#ifdef SG_X_NOATOM // timing experiment: the products are formed, the adds are not issued
+    asm volatile("" ::"v"(p0), "v"(p1), "v"(address), "s"(mask));
+#else
+    unsigned long long saved;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, %1\n\t"
+#ifdef SG_X_ADD32 // timing experiment: 32-bit adds
+                 "ds_add_u32 %2, %3 offset:%5\n\t"
+                 "ds_add_u32 %2, %4 offset:%6\n\t"
+#else
+                 "ds_add_u64 %2, %3 offset:%5\n\t"
+                 "ds_add_u64 %2, %4 offset:%6\n\t"
+#endif
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(saved)
+                 : "s"(mask), "v"(address), "v"(p0), "v"(p1), "n"(OFFSET), "n"(OFFSET + 8)
+                 : "memory");
+#endif
+}
+
 // ---- orientation ---------------------------------------------------------------------------------------
 // One wave (a 64-thread workgroup) per keypoint.  CalculateOrientationHistogram (sift.cpp:1149-1199): the
 // lanes walk the (2r+1)^2 window and add mag*weight into 36-bin LDS histograms with double atomics.  The
@@ -326,7 +380,7 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
 // lane, a superset by a 1e-6 px margin, clipped to the pixels that have a gradient), the wave then writes the
 // intervals' (row, column) pairs into a queue, and takes the queued samples 64 at a time: the reference's
 // acceptance test in double, gradient, and the trilinear spread into 4x4x8 histograms with LDS atomics in 64-bit
-// fixed point (lds_add_fixed; four copies, lane & 3, at a stride that puts them in different banks).
+// fixed point (lds_add_fixed; six copies of the histograms, lane % 6, at a stride that puts them in different banks).
 // So the expensive part runs with full lanes and the window's corners outside the grid are never visited.
 // Against the reference's per-sample formulas three things are algebraically regrouped (results agree to
 // ~1e-15 relative): the rotated coordinates use cos/shw and sin/shw in fused multiply-adds, the window weight
@@ -334,13 +388,53 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
 // E[k] = exp(-k^2/(8 shw^2)), and the orientation coordinate is formed directly in bin units and not wrapped
 // into [0, 8) (the bin index wraps).  HistToDescriptor (sift.cpp:1567-1597): normalise, clamp at 0.2, normalise, min(255,(int)(512 v)).
 
-constexpr int kDescQueue = 768;  // queue entries (samples) per round: a multiple of 64 (full trips), sized so that 20 waves fit a CU's LDS
-constexpr int kDescCopies = 4;
-constexpr int kDescCopyStride = 130; // doubles; 128 bins + 2, so that the copies start 4 banks apart
+constexpr int kDescQueue = 768;  // queue entries (samples) per round: a multiple of 128 (full double trips)
+constexpr int kDescQueuePad = 128; // entries behind the list that the look-ahead of the last two trips reads (copies of the last entry)
+// Histogram copies per wave, and waves per SIMD.  Adds of one instruction that meet in one bin are carried out one
+// after the other, and neighbouring lanes -- neighbouring pixels -- meet often: with one copy the kernel takes 81 ms
+// per 256 frames, with two 54, with four 46.  Four waves per SIMD run as fast as five (the loop is bound by the
+// instructions a SIMD can issue, not by latencies) and leave each wave 10 KB of LDS: room for six copies, 2 % faster.
+#ifndef SG_DESCR_COPIES
+#define SG_DESCR_COPIES 6
+#endif
+#ifndef SG_DESCR_WPE
+#define SG_DESCR_WPE 4
+#endif
+constexpr int kDescCopies = SG_DESCR_COPIES;
+constexpr int kDescCellBins = 9; // a cell's eight orientation bins and a ninth for the upper share of bin 7 (added to bin 0 at the end)
+constexpr int kDescCopyStride = 16 * kDescCellBins + 2; // entries; + 2, so that the copies start 4 banks apart
 constexpr int kDescTab = 256;      // weight table entries of the wide-window variant (one per window row/column)
 constexpr int kDescTabSmall = 128; // ... of the common variant (every radius below 64)
-constexpr int kDescHistPad = 40;   // doubles in front of the histograms: bin addresses are formed from (r0, c0) >= -1
 constexpr int kDescPackRadius = 127; // largest radius whose (row, column) pair fits the 16-bit queue entry
+
+// Inclusive scans over the 64 lanes with data-parallel-primitive moves (no LDS): shifts by 1, 2, 4, 8 inside the rows of
+// 16 lanes, then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into the upper half.  A lane with no source keeps
+// the neutral 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned int dpp_or_zero(unsigned int v)
+{
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned int wave_scan_add(unsigned int v)
+{
+    v += dpp_or_zero<0x111, 0xf>(v); // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);
+    v += dpp_or_zero<0x114, 0xf>(v);
+    v += dpp_or_zero<0x118, 0xf>(v);
+    v += dpp_or_zero<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ unsigned int wave_scan_max(unsigned int v)
+{
+    v = max(v, dpp_or_zero<0x111, 0xf>(v));
+    v = max(v, dpp_or_zero<0x112, 0xf>(v));
+    v = max(v, dpp_or_zero<0x114, 0xf>(v));
+    v = max(v, dpp_or_zero<0x118, 0xf>(v));
+    v = max(v, dpp_or_zero<0x142, 0xa>(v));
+    v = max(v, dpp_or_zero<0x143, 0xc>(v));
+    return v;
+}
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -382,26 +476,35 @@ __device__ __forceinline__ void descr_row_span(int i, double c, double s, double
     cnt = empty ? 0 : max(h - l + 1, 0);
 }
 
-#ifndef SG_DESCR_WPE
-#define SG_DESCR_WPE 5
-#endif
+// What the wave keeps in LDS.  The histograms come last: bin addresses are formed from cell indices (r0, c0) >= -1, five
+// cells below the first bin at the lowest, and the arrays in front keep those addresses above zero.
+template <bool BIG>
+struct DescrLds {
+    double2 lut[kSinLutEntries];                 // direction table (sg_angle_sin_lut)
+    double etab[BIG ? kDescTab : kDescTabSmall]; // etab[k] = E[|k - radius|], k = row or column in the window
+    unsigned short queue[kDescQueue + (BIG ? 2 : 1) * kDescQueuePad]; // (the wide-window variant: 256, for the overrun of its longest row)
+    unsigned long long hist[kDescCopies * kDescCopyStride]; // units of 2^-50 (lds_add_fixed)
+};
+static_assert(offsetof(DescrLds<false>, hist) % 16 == 0 && offsetof(DescrLds<false>, hist) >= 5 * kDescCellBins * 8,
+              "16-byte stores clear the histograms; addresses stay positive");
+static_assert(4 * SG_DESCR_WPE * sizeof(DescrLds<false>) <= 160 * 1024, "the waves of a compute unit share 160 KB");
+
 template <typename T, bool BIG>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE, SG_DESCR_WPE))) void descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img,
-                                              const unsigned int *__restrict__ feat_count,
-                                              uint8_t *__restrict__ desc, size_t desc_img,
-                                              double *__restrict__ prequant, size_t pq_img, unsigned int cap,
-                                              unsigned long long *__restrict__ counters)
+__global__ __launch_bounds__(64)
+__attribute__((amdgpu_waves_per_eu(BIG ? 4 : SG_DESCR_WPE, BIG ? 4 : SG_DESCR_WPE))) void // (the wide tables leave room for fewer)
+descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img, const unsigned int *__restrict__ feat_count,
+        uint8_t *__restrict__ desc, size_t desc_img, double *__restrict__ prequant, size_t pq_img, unsigned int cap,
+        unsigned long long *__restrict__ counters)
 {
-    __shared__ unsigned long long hist_s[kDescHistPad + kDescCopies * kDescCopyStride]; // units of 2^-50 (lds_add_fixed)
-    __shared__ double etab[BIG ? kDescTab : kDescTabSmall]; // etab[k] = E[|k - radius|], k = row or column in the window
-    unsigned long long *hist = hist_s + kDescHistPad;
-    __shared__ unsigned short queue[kDescQueue];
-    __shared__ double2 centres[kAtanLutEntries];
+    __shared__ __align__(16) DescrLds<BIG> lds;
     const int lane = threadIdx.x;
+    unsigned long long *hist = lds.hist;
+    double *etab = lds.etab;
+    unsigned short *queue = lds.queue;
     const int b = blockIdx.y;
     const unsigned int n = min(feat_count[b], cap);
     const FeatRec *fr = frec + (size_t)b * frec_img;
-    sg_atan_lut_fill(centres, lane);
+    sg_sin_lut_fill(lds.lut, lane);
 
     // the next feature's record is loaded while the current one is processed
     FeatRec nxt;
@@ -422,20 +525,29 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
         const int W = 2 * radius + 1;
         const double wcons = -0.125 * inv_shw * inv_shw; // -1/(2*(0.5*4)^2) / shw^2
         // BIG is chosen on the host from the largest radius the parameters allow (64 or more): only then can a
-        // window be too wide for the 16-bit queue entries and the 128-entry weight table.
-        const bool packed = !BIG || radius <= kDescPackRadius;
-        // Sample addresses are unsigned offsets from the pixel one row above and one column left of the
-        // window's first sample (that pixel itself may lie outside the image; it is never read).
+        // window be too wide for the 16-bit queue entries and the 128-entry weight table -- and for planes whose rows
+        // are 16 MB and longer: the queued path forms sample offsets with a 24-bit multiply.
+        const unsigned int pitch_b = (unsigned int)pitch * (unsigned int)sizeof(T);
+        const bool packed = !BIG || (radius <= kDescPackRadius && pitch_b < (1u << 24));
+        // Sample addresses are offsets from the window's first sample (which may lie outside the image: only samples
+        // with four neighbours inside it are listed).
         const T *g0 = (const T *)tab.lv[o][r.interval] + (size_t)b * tab.img_stride[o] +
-                      ((ptrdiff_t)(r.y - radius - 1) * pitch + (r.x - radius - 1));
+                      ((ptrdiff_t)(r.y - radius) * pitch + (r.x - radius));
         const char *gb = reinterpret_cast<const char *>(g0);
         const char *gb_up = reinterpret_cast<const char *>(g0 - pitch), *gb_dn = reinterpret_cast<const char *>(g0 + pitch);
         const double obin_c = (SG_PI - ori) * (4.0 / SG_PI) + 8.0; // + 8: see the drain loop
 
+        {
+            double2 zero2;
+            zero2.x = 0.0;
+            zero2.y = 0.0;
+            double2 *h2 = reinterpret_cast<double2 *>(hist);
 #pragma unroll
-        for (int q = 0; q < (kDescCopies * kDescCopyStride + 63) / 64; q++)
-            if (lane + 64 * q < kDescCopies * kDescCopyStride)
-                hist[lane + 64 * q] = 0ull;
+            for (int q = 0; q < (kDescCopies * kDescCopyStride / 2 + 63) / 64; q++)
+                if (lane + 64 * q < kDescCopies * kDescCopyStride / 2)
+                    h2[lane + 64 * q] = zero2;
+        }
+        static_assert((kDescCopies * kDescCopyStride) % 2 == 0, "cleared in pairs");
         {
             const double e0 = exp((lane * lane) * wcons) * kFixWeightHalf; // both factors of a weight carry 2^-231
             if (lane <= radius && radius + lane < (BIG ? kDescTab : kDescTabSmall)) {
@@ -472,31 +584,54 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                 }
             }
         }
-        unsigned long long *h = hist + (lane & (kDescCopies - 1)) * kDescCopyStride;
+        // the lane's histogram copy, as the byte address of the bin (cell (-1, -1), orientation 0)
+        const unsigned int hbytes = lds_address(hist + (lane % kDescCopies) * kDescCopyStride) - 5u * kDescCellBins * 8u;
+        const unsigned int etab_at = lds_address(etab), lut_at = lds_address(lds.lut);
         wave_lds_fence();
 
-        int row = 0;
+        int row = 0, row_used = 0; // row_used: samples of `row` that earlier rounds have taken
         while (row < W) {
-            // ---- fill: whole rows while they fit (packed), or one row's span computed on the spot ----
+            // ---- fill: rows, one after the other, until the queue is full (packed; a row may end in the next round),
+            // or one row's span computed on the spot ----
             int count = 0, big_lo = 0;
             const int big_row = row;
             if (packed) {
+                unsigned int last_val = 0;
+#ifdef SG_X_NOFILL // timing experiment (with SG_X_NODRAIN): no queue either
+                row = W;
+#endif
                 while (row < W) {
                     const unsigned int sv = row < 64 ? span[0] : (row < 128 ? span[1] : (row < 192 ? span[2] : span[3]));
                     const unsigned int sp = (unsigned int)__builtin_amdgcn_readlane((int)sv, row & 63);
-                    const int cnt = (int)(sp >> 8);
-                    if (count + cnt > kDescQueue)
-                        break;
-                    // a row has at most 2*radius+1 <= 255 columns: four predicated stores (two when every radius < 64)
-                    const unsigned int first = (((unsigned int)row << 8) | (sp & 255u)) + (unsigned int)lane;
+                    const int cnt = (int)(sp >> 8) - row_used;
+                    const int take = min(cnt, kDescQueue - count);
+                    // a row has at most 2*radius+1 <= 255 columns (127 when every radius < 64).  Whole waves store: what
+                    // lands behind the row's last sample is overwritten by the next row or by the padding below (the
+                    // slots behind the queue take the overrun of the last row), and a store under a lane condition
+                    // would cost more than the store (see lds_add_fixed_pair_masked).
+                    const unsigned int first = (((unsigned int)row << 8) | (sp & 255u)) + (unsigned int)row_used;
                     unsigned short *qrow = queue + count + lane;
+                    if (take > 0)
+                        qrow[0] = (unsigned short)(first + (unsigned int)lane);
 #pragma unroll
-                    for (int u = 0; u < (BIG ? 4 : 2); u++)
-                        if (lane + 64 * u < cnt)
-                            qrow[64 * u] = (unsigned short)(first + 64u * u);
-                    count += cnt;
+                    for (int u = 1; u < (BIG ? 4 : 2); u++)
+                        if (take > 64 * u) // (uniform)
+                            qrow[64 * u] = (unsigned short)(first + (unsigned int)lane + 64u * u);
+                    if (take > 0)
+                        last_val = first + (unsigned int)take - 1u;
+                    count += take;
+                    if (take < cnt) {
+                        row_used += take;
+                        break;
+                    }
                     row++;
+                    row_used = 0;
                 }
+                // the slots up to the end of the last double trip, and the two trips of look-ahead behind it, repeat the last entry
+                const int padded = ((count + 127) & ~127) + kDescQueuePad;
+#pragma unroll
+                for (int u = 0; u < 4; u++) // (lanes beyond the end write its last slot again)
+                    queue[min(count + lane + 64 * u, padded - 1)] = (unsigned short)last_val;
                 wave_lds_fence();
             } else if (BIG) {
                 descr_row_span(row - radius, cos_ori, sin_ori, inv_c, inv_s, c_ok, s_ok, Tm, radius, r.x, r.y, rows, cols,
@@ -505,117 +640,171 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_DESCR_WPE
                 row++;
             }
             // ---- drain: double arithmetic on the listed samples ----
-            // The sample list entry and the four neighbour pixels of the lane's next sample are fetched while the
-            // current sample is processed (slots in rotation, see below).
-            struct Sample {
+            // A trip takes 64 listed samples.  Its instruction stream is straight-line up to the histogram adds, and
+            // everything it reads from LDS -- the two weight factors, the direction table entry, and the list entry
+            // that the trip after the next will work on -- is requested before the arithmetic that does not need it, so
+            // that a trip waits for LDS once, and by then the adds of the trip before have drained (LDS operations of a
+            // wave complete in order: a read requested right behind eight adds waits for all of them).  The four neighbour pixels of the next
+            // trip's samples are loaded at the top of the trip from the list entry read one trip earlier; the slots
+            // behind the list repeat its last entry, so every fetch is issued unconditionally and the wait in front of
+            // a slot's first use leaves exactly the younger slot's four loads in flight (vmcnt(4)).
+            struct Slot {
                 unsigned int rc; // (row << 8) | column inside the window (packed), or the column alone (wide windows)
                 T nl, nr, nu, nd;
             };
-            // Every fetch is issued unconditionally (an entry index beyond the list takes the last entry's address
-            // again): loads that sit in no branch let the wait in front of a slot's first use be counted exactly,
-            // so that the two younger slots' loads stay in flight across it.
             const int last_entry = count - 1;
-            auto fetch = [&](int e, Sample &sm) {
-                e = min(e, last_entry);
-                unsigned int r, c;
-                if (packed) {
-                    sm.rc = queue[e];
-                    r = sm.rc >> 8;
-                    c = sm.rc & 255u;
-                } else {
-                    sm.rc = (unsigned int)(big_lo + e);
-                    r = (unsigned int)big_row;
-                    c = sm.rc;
-                }
-                const unsigned int off = ((r + 1u) * (unsigned int)pitch + (c + 1u)) * (unsigned int)sizeof(T);
-                const char *p8 = gb + (size_t)off;
-                sm.nl = *reinterpret_cast<const T *>(p8 - sizeof(T));
-                sm.nr = *reinterpret_cast<const T *>(p8 + sizeof(T));
-                sm.nu = *reinterpret_cast<const T *>(gb_up + (size_t)off);
-                sm.nd = *reinterpret_cast<const T *>(gb_dn + (size_t)off);
+            auto entry_of = [&](int e0) -> unsigned int { // list entries e0 .. e0+63
+                if (packed)
+                    return queue[e0 + lane];
+                return (unsigned int)(big_lo + min(e0 + lane, last_entry));
             };
-            auto process = [&](const Sample &sm, bool listed) {
-                const unsigned int sr = packed ? sm.rc >> 8 : (unsigned int)big_row, sc = packed ? sm.rc & 255u : sm.rc;
+            auto issue_loads = [&](unsigned int rc, Slot &sl) {
+                sl.rc = rc;
+                unsigned int off;
+                if (packed)
+                    off = mad_u24(rc >> 8, pitch_b, (rc & 255u) * (unsigned int)sizeof(T)); // (pitch_b < 2^24 on this path)
+                else
+                    off = (unsigned int)big_row * pitch_b + rc * (unsigned int)sizeof(T);
+#ifdef SG_X_NOLOAD // timing experiment: no pixel loads
+                sl.nl = (T)off;
+                sl.nr = (T)(off + 3u);
+                sl.nu = (T)(off ^ 5u);
+                sl.nd = (T)(off + 9u);
+#else
+                const char *p8 = gb + (size_t)off;
+                sl.nl = *reinterpret_cast<const T *>(p8 - sizeof(T));
+                sl.nr = *reinterpret_cast<const T *>(p8 + sizeof(T));
+                sl.nu = *reinterpret_cast<const T *>(gb_up + (size_t)off);
+                sl.nd = *reinterpret_cast<const T *>(gb_dn + (size_t)off);
+#endif
+            };
+            // one trip: works on `cur`; starts the loads of `nxt` from rc_nxt; reads the list entries e_ahead.. into rc_ahead
+            auto trip = [&](const Slot &cur, bool listed, Slot &nxt, unsigned int rc_nxt, int e_ahead, unsigned int &rc_ahead) {
+                issue_loads(rc_nxt, nxt);
+                const unsigned int sr = packed ? cur.rc >> 8 : (unsigned int)big_row, sc = packed ? cur.rc & 255u : cur.rc;
+                double e_r = 0.0, e_c = 0.0;
+#ifdef SG_X_NOLDSREAD // timing experiment: no LDS reads for the weights and the table entry
+                e_r = (double)sr;
+                e_c = (double)sc;
+#else
+                if (!BIG || packed) {
+                    e_r = *(const __attribute__((address_space(3))) double *)(size_t)(etab_at + sr * 8u);
+                    e_c = *(const __attribute__((address_space(3))) double *)(size_t)(etab_at + sc * 8u);
+                }
+#endif
+                rc_ahead = entry_of(e_ahead);
+                // (1) what needs neither the pixels nor LDS: the sample's place in the grid, shifted by one cell
+                // (xs = xbin + 1 in (0, 5) for an accepted sample), so that truncation is the floor and the cell index
+                // is never negative
                 const int i = (int)sr - radius, jj = (int)sc - radius;
-                const double dx = (double)sm.nr - (double)sm.nl;
-                const double dy = (double)sm.nd - (double)sm.nu;
-                // grid coordinates shifted by one cell (xs = xbin + 1 in (0, 5) for an accepted sample), so that
-                // truncation is the floor and the cell index is never negative
                 const double xs = __builtin_fma(cs, (double)jj, __builtin_fma(-ss, (double)i, 2.5));
                 const double ys = __builtin_fma(ss, (double)jj, __builtin_fma(cs, (double)i, 2.5));
-                if (listed && xs > 0.0 && xs < 5.0 && ys > 0.0 && ys < 5.0) {
-                    const double grad_mag = sg_sqrt_sum(__builtin_fma(dx, dx, dy * dy));
-                    // obin = ((pi - atan2(dy,dx)) - ori) * 8/(2 pi) = obin_c - atan2(dy,dx) in units of pi/4; the
-                    // histogram index below wraps by itself, so the angle is not brought into [0, 2 pi) first
-                    // (obin_c carries +8, which keeps the coordinate positive and leaves the index unchanged)
-                    const double ax = fabs(dx), ay = fabs(dy);
-                    const double mx = __builtin_fmax(ax, ay), mn = __builtin_fmin(ax, ay);
-                    double kq;
-                    const double au = sg_atan_split_lut(mn, mx, centres, kq);
-                    double q = __builtin_fma(au, 4.0 / SG_PI, kq);
-                    q = ay > ax ? 2.0 - q : q;
-                    q = dx < 0.0 ? 4.0 - q : q;
-                    const double obin = obin_c - __builtin_copysign(q, dy);
-                    double weight;
-                    if (BIG && !packed)
-                        weight = exp((i * i + jj * jj) * wcons) * kFixWeight;
-                    else
-                        weight = etab[sr] * etab[sc];
-                    const double mag = grad_mag * weight;
-                    // InterpHistEntry: cell indices r1 = r0 + 1, c1 = c0 + 1 in 0..4, fractions by v_fract_f64
-                    const int r1 = (int)ys, c1 = (int)xs, o0 = (int)obin;
-                    const double d_r = __builtin_amdgcn_fract(ys), d_c = __builtin_amdgcn_fract(xs),
-                                 d_o = __builtin_amdgcn_fract(obin);
-                    // the eight bins lie at fixed distances from the (r0, c0) cell in the two orientation columns
-                    unsigned long long *hb = h + (r1 * 4 + c1) * 8 - 40;
-                    unsigned long long *hb0 = hb + (o0 & 7), *hb1 = hb + ((o0 + 1) & 7);
-                    const double w_o1 = d_o * kFixFrac, w_o0 = kFixFrac - w_o1; // (1 - d_o) and d_o, scaled (exactly)
-                    // mag split over the two rows, each row over the two columns: the far share is a product, the near
-                    // share the remainder
-                    const double v_r1 = mag * d_r, v_r0 = mag - v_r1;
-#pragma unroll
-                    for (int rr = 0; rr <= 1; rr++) {
-                        const unsigned int rb = (unsigned int)(r1 + rr - 1);
-                        if (rb < 4u) {
-                            const double v_r = rr == 0 ? v_r0 : v_r1;
-                            const double v_c1 = v_r * d_c, v_c0 = v_r - v_c1;
-#pragma unroll
-                            for (int cc = 0; cc <= 1; cc++) {
-                                const unsigned int cb = (unsigned int)(c1 + cc - 1);
-                                if (cb < 4u) {
-                                    const double v_c = cc == 0 ? v_c0 : v_c1;
-                                    lds_add_fixed(hb0 + (rr * 4 + cc) * 8, v_c, w_o0);
-                                    lds_add_fixed(hb1 + (rr * 4 + cc) * 8, v_c, w_o1);
-                                }
-                            }
-                        }
-                    }
-                }
+                // 0 < v < 5 on the high word alone: 5.0 is 0x40140000:00000000, so v >= 5 (and every NaN) has a high
+                // word of 0x40140000 or more, a negative v (and -0) one of 0x80000000 or more, +0 has 0, which the
+                // subtraction wraps; a positive v below 2^-1042 (high word 0 as well) cannot come out of these sums of
+                // products of numbers of ordinary size.
+                const unsigned int hx = (unsigned int)((unsigned long long)__double_as_longlong(xs) >> 32);
+                const unsigned int hy = (unsigned int)((unsigned long long)__double_as_longlong(ys) >> 32);
+                // The sample adds to cell row r1 - 1 if 1 <= ys < 5 and to row r1 if 0 < ys < 4, and likewise in the
+                // columns (the cells that exist around an accepted sample: 0 < xs, ys < 5); each of the four tests is
+                // one unsigned compare of the shifted high word, and the four wave masks stay in scalar registers
+                // until the adds.
+                const unsigned long long m_listed = __builtin_amdgcn_ballot_w64(listed);
+                const unsigned long long m_r0 = __builtin_amdgcn_ballot_w64(hy - 0x3FF00000u < 0x00240000u) & m_listed;
+                const unsigned long long m_r1 = __builtin_amdgcn_ballot_w64(hy - 1u < 0x400FFFFFu) & m_listed;
+                const unsigned long long m_c0 = __builtin_amdgcn_ballot_w64(hx - 0x3FF00000u < 0x00240000u);
+                const unsigned long long m_c1 = __builtin_amdgcn_ballot_w64(hx - 1u < 0x400FFFFFu);
+                const int c1 = (int)xs, r1 = (int)ys;
+                const double d_r = __builtin_amdgcn_fract(ys), d_c = __builtin_amdgcn_fract(xs);
+                __builtin_amdgcn_sched_barrier(0);
+                // (2) the pixels: gradient, the seed of 1/magnitude, and from it the direction table entry to read
+                const double dx = (double)cur.nr - (double)cur.nl;
+                const double dy = (double)cur.nd - (double)cur.nu;
+                const double m2 = __builtin_fma(dx, dx, dy * dy);
+                const double y = __builtin_amdgcn_rsq(__builtin_fmax(m2, 1e-300));
+                const double ax = fabs(dx), ay = fabs(dy);
+                const double mx = __builtin_fmax(ax, ay), mn = __builtin_fmin(ax, ay);
+                double k_dbl;
+                const unsigned int lut_off = sg_sin_lut_index(mn, y, k_dbl);
+                double2 ck; // {cos, angle} of the centre
+#ifdef SG_X_NOLDSREAD
+                ck.x = (double)lut_off;
+                ck.y = k_dbl;
+#else
+                ck.x = *(const __attribute__((address_space(3))) double *)(size_t)(lut_at + lut_off);
+                ck.y = *(const __attribute__((address_space(3))) double *)(size_t)(lut_at + lut_off + 8u);
+#endif
+                // (3) while that read is under way: sqrt as in sg_sqrt_sum (its seed and residual also serve the direction)
+                const double g = m2 * y, hh = 0.5 * y;
+                const double res = __builtin_fma(-hh, g, 0.5);
+                const double grad_mag = __builtin_fma(g, res, g);
+                const double mxk = mx * k_dbl;
+                __builtin_amdgcn_sched_barrier(0);
+                // (4) everything that was read from LDS is used from here on.
+                // obin = ((pi - atan2(dy,dx)) - ori) * 8/(2 pi) = obin_c - atan2(dy,dx) in units of pi/4; the
+                // histogram index below wraps by itself, so the angle is not brought into [0, 2 pi) first
+                // (obin_c carries +8, which keeps the coordinate positive and leaves the index unchanged)
+                double q = sg_angle_sin_lut(mn, mxk, y, res, ck);
+                q = ay > ax ? 2.0 - q : q;
+                q = dx < 0.0 ? 4.0 - q : q;
+                const double obin = obin_c - __builtin_copysign(q, dy);
+                double weight;
+                if (BIG && !packed)
+                    weight = exp((i * i + jj * jj) * wcons) * kFixWeight;
+                else
+                    weight = e_r * e_c;
+                const double mag = grad_mag * weight;
+                // InterpHistEntry: cell indices r1 = r0 + 1, c1 = c0 + 1 in 0..4, fractions by v_fract_f64
+                const int o0 = (int)obin;
+                const double d_o = __builtin_amdgcn_fract(obin);
+                // the eight bins lie at fixed distances from the (r0, c0) cell's bin o0; the bin above o0 is the
+                // next entry (the ninth entry of a cell stands for bin 0)
+                unsigned int hb = (((unsigned int)o0 & 7u) << 3) + hbytes;
+                hb = mad_u24((unsigned int)c1, kDescCellBins * 8u, hb);
+                hb = mad_u24((unsigned int)r1, 4u * kDescCellBins * 8u, hb);
+                const double w_o1 = d_o * kFixFrac, w_o0 = kFixFrac - w_o1; // (1 - d_o) and d_o, scaled (exactly)
+                // mag split over the two rows, each row over the two columns: the far share is a product, the near
+                // share the remainder
+                const double v_r1 = mag * d_r, v_r0 = mag - v_r1;
+                const double v_01 = v_r0 * d_c, v_00 = v_r0 - v_01;
+                const double v_11 = v_r1 * d_c, v_10 = v_r1 - v_11;
+                lds_add_fixed_pair_masked<0>(hb, v_00, w_o0, w_o1, m_r0 & m_c0);
+                lds_add_fixed_pair_masked<kDescCellBins * 8>(hb, v_01, w_o0, w_o1, m_r0 & m_c1);
+                lds_add_fixed_pair_masked<4 * kDescCellBins * 8>(hb, v_10, w_o0, w_o1, m_r1 & m_c0);
+                lds_add_fixed_pair_masked<5 * kDescCellBins * 8>(hb, v_11, w_o0, w_o1, m_r1 & m_c1);
             };
-            // Two sample slots in rotation (the loop body is written twice): the loads of a slot are issued while the
-            // other slot is processed, and the wait in front of a slot's use leaves the younger slot's four loads in
-            // flight (vmcnt(4)).  (A third slot, two trips of distance, was measured 1.5 % slower.)
             trips += (unsigned int)((count + 63) >> 6);
+#ifdef SG_X_NODRAIN // timing experiment: everything but the trips
+            if (count < 0) {
+#else
             if (count > 0) {
-                Sample s0, s1;
-                fetch(lane, s0);
+#endif
+                Slot s0, s1;
+                unsigned int rc_a = entry_of(0), rc_b = entry_of(64);
+                // (both entries are in registers before the loop is entered: a read still pending at its head would
+                // put a wait for LDS there, which inside the loop would wait for the histogram adds of the trip before)
+                asm volatile("" : "+v"(rc_a), "+v"(rc_b));
+                issue_loads(rc_a, s0);
                 for (int base = 0; base < count; base += 128) { // count is the wave's: a uniform loop
-                    const int e = base + lane;
-                    fetch(e + 64, s1);
-                    process(s0, e < count);
-                    fetch(e + 128, s0);
-                    process(s1, e + 64 < count);
+                    const int left = count - base;
+                    trip(s0, lane < left, s1, rc_b, base + 128, rc_a);
+                    trip(s1, lane < left - 64, s0, rc_a, base + 192, rc_b);
                 }
             }
             wave_lds_fence();
         }
 
-        // lane L finishes bins 2L and 2L+1
+        // lane L finishes bins 2L and 2L+1: orientations 2(L & 3) and the next of cell L >> 2
         unsigned long long u0 = 0, u1 = 0;
+        {
+            const int cell = (lane >> 2) * kDescCellBins, ob = (lane & 3) * 2;
 #pragma unroll
-        for (int q2 = 0; q2 < kDescCopies; q2++) {
-            u0 += hist[q2 * kDescCopyStride + 2 * lane];
-            u1 += hist[q2 * kDescCopyStride + 2 * lane + 1];
+            for (int q2 = 0; q2 < kDescCopies; q2++) {
+                u0 += hist[q2 * kDescCopyStride + cell + ob];
+                u1 += hist[q2 * kDescCopyStride + cell + ob + 1];
+                const unsigned long long wrapped = hist[q2 * kDescCopyStride + cell + 8];
+                u0 += ob == 0 ? wrapped : 0ull;
+            }
         }
         // whole units to double (one rounding: the high word's 2^32 multiples and the low word are both exact)
         double v0 = __builtin_fma((double)(unsigned int)(u0 >> 32), 4294967296.0, (double)(unsigned int)u0) * (1.0 / kFixScale);
@@ -655,22 +844,24 @@ void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_str
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
                   int max_radius, int B, int prec, unsigned long long *counters, hipStream_t s)
 {
-    unsigned int blocks = feature_blocks(cap, B, 384, 384, env().descr_waves);
+    unsigned int waves = feature_blocks(cap, B, 384, 384, env().descr_waves);
     // about four features per wave at least (the capacity is about two and a half times a natural image's count): with
     // fewer, the set-up of a wave and the gaps between generations of waves cost more than the finer balance gains
-    // -- and whole generations (20 waves per compute unit are resident): a last generation of a few waves costs as much
+    // -- and whole generations (16 waves per compute unit are resident): a last generation of a few waves costs as much
     // time as a full one
-    if (env().descr_waves <= 0 && blocks > cap / 10) {
-        const unsigned int gen = 20u * (unsigned int)env().n_cu, nb = (unsigned int)(B > 0 ? B : 1);
+    if (env().descr_waves <= 0 && waves > cap / 10) {
+        const unsigned int gen = 4u * SG_DESCR_WPE * (unsigned int)env().n_cu, nb = (unsigned int)(B > 0 ? B : 1);
         unsigned int total = cap / 10 * nb;
         total = total > gen ? total - total % gen : gen; // at least the one generation that costs nothing extra
         const unsigned int per_image = total / nb > 384u ? total / nb : 384u;
-        blocks = per_image < blocks ? per_image : blocks;
+        waves = per_image < waves ? per_image : waves;
     }
-    if (blocks == 0)
+    if (waves == 0)
         return;
-    dim3 g(blocks, B);
-    const bool big = 2 * max_radius + 1 > kDescTabSmall; // a window row or column beyond the small table
+    dim3 g(waves, B);
+    bool big = 2 * max_radius + 1 > kDescTabSmall; // a window row or column beyond the small table
+    for (int o = 0; o < tab.octaves; o++) // ... or a row of 16 MB
+        big = big || (size_t)tab.pitch[o] * (prec == SG_F64 ? 8u : 4u) >= ((size_t)1 << 24);
 #define SG_DESCR_LAUNCH(TT, BB)                                                                                       \
     descr_k<TT, BB><<<g, 64, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,         \
                                      pq_img_stride, cap, counters)

@@ -19,6 +19,14 @@ __device__ __forceinline__ double sg_fma3(double a, double b, double c)
     return d;
 }
 
+// a*b + c with c in scalar registers (a wave-uniform value, e.g. a constant): no vector register is spent on it.
+__device__ __forceinline__ double sg_fma3s(double a, double b, double c_uniform)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c_uniform));
+    return d;
+}
+
 // sqrt for 0 <= x in the normal range: v_rsq_f64 seed, one coupled Newton-Raphson step (Goldschmidt form)
 // and one residual correction; within 1 ulp.
 __device__ __forceinline__ double sg_sqrt(double x)
@@ -98,42 +106,80 @@ __device__ __forceinline__ double sg_div_sum(double n, double d)
     return n * r;
 }
 
-// sg_atan_split with that division, the odd series cut after u^11/11, and the centre picked from a 35-entry table
-// by the single-precision ratio: entry i serves
-// mn/mx in [i/33, (i+1)/33) and holds (tan(k pi/16), k/4) for the k nearest to atan((i + 1/2)/33), so that
-// |u| <= tan(pi/32 + 1/66) = 0.114 and the series' truncation stays below 5e-14.  Two conversions, one v_rcp_f32, two
-// single-precision products and one LDS read replace four double products, four compares and four selects.  A zero
-// gradient (0/0) converts to entry 0 and gives u = 0.
-constexpr int kAtanLutEntries = 35;
-__device__ __forceinline__ void sg_atan_lut_fill(double2 *lut, int lane, bool radians = false)
+// Direction of a gradient from its magnitude's reciprocal, with no division.  The sample loop already holds
+// y ~ 1/sqrt(dx^2+dy^2) (the v_rsq_f64 seed) and the residual r of its Newton step, so sin(theta) = mn*y for the
+// angle theta in [0, pi/4] of (mx, mn) costs one product.  sin(theta), rounded to a multiple of 1/32 by adding
+// 2^47 (the sum's low mantissa bits are then the integer k = 0..23), picks a centre phi_k with sin(phi_k) = k/32; the
+// table holds cos(phi_k) and phi_k in units of pi/4 (sin(phi_k) = k/32 comes back out of the sum, exactly).  Then
+//   u = sin(theta - phi_k) = (mn * cos(phi_k) - mx * k/32) / mag,   |u| <= 0.0221,
+// with 1/mag = y(1 + r), and theta - phi_k = asin(u) by its series to u^7 (truncation below 1e-16).  The
+// reciprocal carries the seed's error squared (2^-45), which the size of u reduces to 7e-16 of a radian.
+// Eleven double-precision operations in all, against a v_rcp_f64, fifteen more and a single-precision index computation
+// for the quotient form.  A zero gradient gives k = 0, U = 0 and the angle 0.
+constexpr int kSinLutEntries = 24;
+__device__ const double kSinLut[kSinLutEntries][2] = { // (generated by tools/gen_sin_lut.py)
+    {0x1.0000000000000p+0, 0x0.0p+0},
+    {0x1.ffbffbff7fec0p-1, 0x1.46009d2eee445p-5},
+    {0x1.feffbfdfebf1fp-1, 0x1.462972893d260p-4},
+    {0x1.fdbeba917c3f5p-1, 0x1.e9a49d9c4ecf6p-4},
+    {0x1.fbfbf7ebc755fp-1, 0x1.46cdde5cc9717p-3},
+    {0x1.f9b61d0237250p-1, 0x1.991ceda75d74cp-3},
+    {0x1.f6eb62d27730dp-1, 0x1.ebd5c6ffa1500p-3},
+    {0x1.f3998f1b1886cp-1, 0x1.1f87d9e8cdc56p-2},
+    {0x1.efbdeb14f4edap-1, 0x1.49719f07a5377p-2},
+    {0x1.eb5537b1434dap-1, 0x1.73b53d57e94afp-2},
+    {0x1.e65b9edeba38ep-1, 0x1.9e60aff8536d7p-2},
+    {0x1.e0cca12e97895p-1, 0x1.c9831560c195bp-2},
+    {0x1.daa2fefaae1d8p-1, 0x1.f52cebe2d7795p-2},
+    {0x1.d3d89be176072p-1, 0x1.10b82d6ef85b0p-1},
+    {0x1.cc665b0328622p-1, 0x1.2730c645f555fp-1},
+    {0x1.c443f1d4d22afp-1, 0x1.3e0b8edacdea9p-1},
+    {0x1.bb67ae8584caap-1, 0x1.5555555555556p-1},
+    {0x1.b1c62db2564fep-1, 0x1.6d1cc1f0b5912p-1},
+    {0x1.a751f9447b724p-1, 0x1.8572cc9d34757p-1},
+    {0x1.9bfb076d236ebp-1, 0x1.9e6b58ffe0d2fp-1},
+    {0x1.8fae0c15ad38ap-1, 0x1.b81e0985cc8eap-1},
+    {0x1.8253878ae2e09p-1, 0x1.d2a7638e7e783p-1},
+    {0x1.73ce704fb7b23p-1, 0x1.ee2a6e8b77d33p-1},
+    {0x1.63fa3f3c02962p-1, 0x1.05698a0e94436p+0},
+};
+constexpr double kAsinC0 = 0x1.45f306dc9c883p+0; // 4/pi: asin(u)/(pi/4) = u (c0 + c1 u^2 + c2 u^4 + c3 u^6)
+constexpr double kAsinC1 = 0x1.b2995e7b7b604p-3; // c0 / 6
+constexpr double kAsinC2 = 0x1.8723a1d588a36p-4; // c0 * 3/40
+constexpr double kAsinC3 = 0x1.d1a452f204304p-5; // c0 * 5/112
+
+// Copies the table into LDS; call with `lane` covering 0..kSinLutEntries-1, then make the stores visible.
+__device__ __forceinline__ void sg_sin_lut_fill(double2 *lut, int lane)
 {
-    if (lane < kAtanLutEntries) {
-        const float mid = ((float)lane + 0.5f) * (1.0f / 33.0f);
-        int k = (int)(atanf(mid) * (16.0f / 3.14159265f) + 0.5f);
-        k = k > 4 ? 4 : k;
+    if (lane < kSinLutEntries) {
         double2 e;
-        e.x = k == 0 ? 0.0 : k == 1 ? 0.19891236737965800 : k == 2 ? 0.41421356237309503 : k == 3 ? 0.66817863791929888 : 1.0;
-        e.y = radians ? 0.19634954084936207 * k : 0.25 * k; // k pi/16, or k/4 in units of pi/4
+        e.x = kSinLut[lane][0];
+        e.y = kSinLut[lane][1];
         lut[lane] = e;
     }
 }
 
-__device__ __forceinline__ double sg_atan_split_lut(double mn, double mx, const double2 *lut, double &k_term)
+// The table entry for the direction of (mx, mn), 0 <= mn <= mx: its byte offset (16 k), and the centre's sine k/32.
+// y = the reciprocal-square-root seed of mx^2 + mn^2 (clamped away from zero).
+__device__ __forceinline__ unsigned int sg_sin_lut_index(double mn, double y, double &sin_k)
 {
-    const float t = (float)mn * __builtin_amdgcn_rcpf((float)mx);
-    const unsigned int idx = (unsigned int)(t * 33.0f); // NaN -> 0; a ratio that rounds above 1 -> entry 33
-    const double2 ck = lut[idx < (unsigned int)kAtanLutEntries ? idx : kAtanLutEntries - 1];
-    k_term = ck.y;
-    const double num = __builtin_fma(-ck.x, mx, mn);
-    const double den = fmax(__builtin_fma(ck.x, mn, mx), 1e-300);
-    const double u = sg_div_sum(num, den);
-    const double z = u * u;
-    double p = -1.0 / 11.0;
-    p = sg_fma3(p, z, 1.0 / 9.0);
-    p = sg_fma3(p, z, -1.0 / 7.0);
-    p = sg_fma3(p, z, 1.0 / 5.0);
-    p = sg_fma3(p, z, -1.0 / 3.0);
-    return __builtin_fma(u * z, p, u);
+    const double t = __builtin_fma(mn, y, 0x1p47);
+    sin_k = t - 0x1p47;
+    return (unsigned int)__double_as_longlong(t) << 4;
+}
+
+// atan(mn/mx) in units of pi/4 from the entry ck = {cos, angle} and mxk = mx * sin_k; r = the residual
+// of the Newton step on y (1/mag = y + y*r).
+__device__ __forceinline__ double sg_angle_sin_lut(double mn, double mxk, double y, double r, double2 ck)
+{
+    const double w = __builtin_fma(mn, ck.x, -mxk);
+    const double wy = w * y;
+    const double U = __builtin_fma(wy, r, wy);
+    const double z = U * U;
+    double p = sg_fma3s(z, kAsinC3, kAsinC2); // (kAsinC3 in vector registers, the other three coefficients in scalar ones)
+    p = sg_fma3s(p, z, kAsinC1);
+    p = sg_fma3s(p, z, kAsinC0);
+    return __builtin_fma(U, p, ck.y);
 }
 
 // centres[k] = (tan(k*pi/16), k*pi/16) if radians, else (tan(k*pi/16), k/4) -- the angle in units of pi/4 -- for

@@ -151,13 +151,19 @@ def measured_traffic(kernel, tname, batch, width, height):
 # (distinct addresses; same-address lanes serialise), reads 1.8.
 ISSUE_NS = {"valu_f64": 2.1, "transcendental_f64": 7.4, "valu_other": 1.9}
 LDS_NS = {"lds_u64_adds": 3.5, "lds_f64_adds": 6.8, "lds_other": 1.8}
+# What an LDS instruction costs the SIMD that issues it, beside double-precision work of the other waves
+# (profiles/ubench/issue_mix.hip, profiles/r03/issue_mix.txt: 32 ds_read_b64 between 32 v_fma_f64 add 2.4 ns each; the
+# 64-bit adds from the descriptor kernel run with and without them, profiles/r03/descr_variants.txt: 5-6.7 ms over
+# 150.8 M trips of 8 adds on 1024 SIMDs = 4.2-5.7 ns each).
+SIMD_NS_LDS = {"adds": 4.2, "other": 2.4}
 
 
 def valu_roofline(kernel, trips, kernel_ms, n_simd=1024, n_cu=256):
     """Prices a histogram kernel against the vector issue rate and the LDS pipe: static instruction counts of its
     sample loop (profiles/isa_counts.json, from the ISA) x measured 64-sample trips x the measured cost of an
     instruction, against the kernel's measured time.  The loop's per-feature set-up is not counted, so the fractions
-    are lower bounds."""
+    are lower bounds.  simd_issue_* adds what the loop's LDS instructions cost the issuing SIMD: the kernel's time
+    follows the sum of what a SIMD has to issue, not the busiest pipe."""
     try:
         isa = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))[kernel]
     except (OSError, ValueError, KeyError):
@@ -167,15 +173,19 @@ def valu_roofline(kernel, trips, kernel_ms, n_simd=1024, n_cu=256):
     f64 = isa["valu_f64"] - isa["transcendental_f64"]
     valu_ns = f64 * ISSUE_NS["valu_f64"] + isa["transcendental_f64"] * ISSUE_NS["transcendental_f64"] + \
         isa["valu_other"] * ISSUE_NS["valu_other"]
+    n_adds = isa.get("lds_u64_adds", 0) + isa.get("lds_f64_adds", 0)
     adds = isa.get("lds_u64_adds", 0) * LDS_NS["lds_u64_adds"] + isa.get("lds_f64_adds", 0) * LDS_NS["lds_f64_adds"]
-    lds_other = isa["lds"] - isa.get("lds_u64_adds", 0) - isa.get("lds_f64_adds", 0)
+    lds_other = isa["lds"] - n_adds
     lds_ns = adds + lds_other * LDS_NS["lds_other"]
+    simd_ns = valu_ns + n_adds * SIMD_NS_LDS["adds"] + lds_other * SIMD_NS_LDS["other"]
     issue_ms = trips * valu_ns / n_simd * 1e-6
     lds_ms = trips * lds_ns / n_cu * 1e-6
+    simd_ms = trips * simd_ns / n_simd * 1e-6
     return {"kernel": kernel, "trips_64_samples": int(trips), "kernel_ms": kernel_ms,
             "valu_instructions_per_trip": isa["valu_f64"] + isa["valu_other"], "valu_f64_per_trip": isa["valu_f64"],
             "valu_issue_ms": issue_ms, "valu_frac": issue_ms / kernel_ms,
-            "lds_instructions_per_trip": isa["lds"], "lds_pipe_ms": lds_ms, "lds_frac": lds_ms / kernel_ms}
+            "lds_instructions_per_trip": isa["lds"], "lds_pipe_ms": lds_ms, "lds_frac": lds_ms / kernel_ms,
+            "simd_issue_ms": simd_ms, "simd_issue_frac": simd_ms / kernel_ms}
 
 
 def batch_check_and_latency(sift_amd, torch, dev, dev_index, prec, W, H, cap, frames, frame_bytes, first, B, out, counts):

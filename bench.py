@@ -506,6 +506,24 @@ def main():
     cnts = [torch.zeros(B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
     exchange = xctx = comm = None
     do_exchange = world > 1 or args.exchange
+    # With several ranks, the set-up of the C ABI's own RCCL communicator and the first all-gather through it (in the
+    # warm-up) are the first time that path meets real peers.  Should either never return, the run ends with a message
+    # instead of sitting until the caller's time limit: SIFT_BENCH_EXCHANGE=torch then takes the same exchange through
+    # torch.distributed instead.
+    watchdog = None
+    if world > 1 and dist.get_backend() == "nccl" and os.environ.get("SIFT_BENCH_EXCHANGE", "abi") != "torch":
+        import threading
+
+        def stuck():
+            sys.stderr.write("bench.py rank %d: the RCCL set-up or the warm-up exchange (sg_allgather_features) did not "
+                             "finish in 300 s; rerun with SIFT_BENCH_EXCHANGE=torch to exchange through "
+                             "torch.distributed\n" % rank)
+            sys.stderr.flush()
+            os._exit(4)
+
+        watchdog = threading.Timer(300.0, stuck)
+        watchdog.daemon = True
+        watchdog.start()
     if do_exchange:
         # The exchange step: all-gather-v of the ranks' feature sets (sg_allgather_features: counts first, then one
         # grouped set of RCCL broadcasts into an unpadded buffer).  It runs on the stream of a context of its own, so
@@ -614,22 +632,8 @@ def main():
             dist.barrier()
 
     # ---- warmup ----
-    # With several ranks the first all-gather through the C ABI's own RCCL binding happens here.  Should it never
-    # return (a communicator that cannot form, say), the run ends with a message instead of sitting until the caller's
-    # time limit: SIFT_BENCH_EXCHANGE=torch then takes the same exchange through torch.distributed instead.
-    watchdog = None
-    if world > 1 and xctx is not None:
-        import threading
-
-        def stuck():
-            sys.stderr.write("bench.py rank %d: the warm-up exchange (sg_allgather_features over RCCL) did not finish in "
-                             "300 s; rerun with SIFT_BENCH_EXCHANGE=torch to exchange through torch.distributed\n" % rank)
-            sys.stderr.flush()
-            os._exit(4)
-
-        watchdog = threading.Timer(300.0, stuck)
-        watchdog.daemon = True
-        watchdog.start()
+    # (With several ranks the first all-gather through the C ABI's own RCCL binding happens here, under the watchdog
+    # started in front of the communicator's set-up.)
     for s in range(max(WU, 1 if world > 1 else 0)):
         submit(s)
     drain()

@@ -26,6 +26,7 @@ struct ThreadState {
     int max_w = 0, max_h = 0;
     double sigma = 0;
     int nointerval = -1;
+    int precision = -1; // the sg_precision the context was built with
     size_t max_features = 0; // 0: the library's default density; raised after an image overflowed it
     int device = 0;
     int status = SG_OK;
@@ -41,6 +42,25 @@ struct ThreadState {
             sg_destroy(ctx);
     }
 };
+
+// The pyramid arithmetic of contexts created from now on (SiftSetPrecision; -1: the environment decides on first use).
+std::atomic<int> g_precision(-1);
+int precision_now()
+{
+    int p = g_precision.load();
+    if (p < 0) {
+        const char *e = std::getenv("SIFT_GPU_PRECISION");
+        p = SG_F64;
+        if (e && (!std::strcmp(e, "fused") || !std::strcmp(e, "f64_fma")))
+            p = SG_F64_FMA;
+        else if (e && (!std::strcmp(e, "single") || !std::strcmp(e, "f32")))
+            p = SG_F32;
+        int expected = -1;
+        g_precision.compare_exchange_strong(expected, p);
+        p = g_precision.load();
+    }
+    return p;
+}
 
 // Wire records into the caller's vector, behind what it holds.  resize() would zero 1120 bytes per new record before
 // they are filled (a Keypoint is a plain struct); instead the records are expanded a few dozen at a time into a buffer
@@ -80,8 +100,9 @@ sg_ctx *context_for(int w, int h, double sigma, int nointerval, size_t min_featu
         w = 2;
     if (h < 2)
         h = 2;
+    const int precision = precision_now();
     const bool fits = tls.ctx && w <= tls.max_w && h <= tls.max_h && sigma == tls.sigma &&
-                      nointerval == tls.nointerval && min_features <= tls.max_features;
+                      nointerval == tls.nointerval && precision == tls.precision && min_features <= tls.max_features;
     if (fits)
         return tls.ctx;
     if (min_features > tls.max_features)
@@ -94,6 +115,7 @@ sg_ctx *context_for(int w, int h, double sigma, int nointerval, size_t min_featu
     sg_default_params(&p);
     p.sigma = sigma;
     p.nointerval = nointerval;
+    p.precision = precision;
     p.max_width = w > tls.max_w ? w : tls.max_w;
     p.max_height = h > tls.max_h ? h : tls.max_h;
     p.max_batch = 1;
@@ -110,6 +132,7 @@ sg_ctx *context_for(int w, int h, double sigma, int nointerval, size_t min_featu
     tls.max_h = p.max_height;
     tls.sigma = sigma;
     tls.nointerval = nointerval;
+    tls.precision = precision;
     return tls.ctx;
 }
 
@@ -397,6 +420,7 @@ private:
         sg_default_params(&p);
         p.sigma = sigma;
         p.nointerval = ni;
+        p.precision = precision_now(); // (SiftSetPrecision drops the shared contexts, so a lane never mixes two)
         p.max_width = w > k->max_w ? w : k->max_w;
         p.max_height = h > k->max_h ? h : k->max_h;
         p.device = device_;
@@ -816,6 +840,17 @@ void SiftSetBatching(int max_batch)
     }
     g_batchers.clear();
     g_batching.store(max_batch);
+}
+void SiftSetPrecision(int precision)
+{
+    const int p = precision == SIFT_FUSED ? SG_F64_FMA : (precision == SIFT_SINGLE ? SG_F32 : SG_F64);
+    std::lock_guard<std::mutex> lk(g_batchers_mutex);
+    for (auto &kv : g_batchers) {
+        kv.second->destroy();
+        delete kv.second;
+    }
+    g_batchers.clear();
+    g_precision.store(p); // per-thread contexts notice at their next call
 }
 void SiftReleaseContext()
 {

@@ -8,6 +8,9 @@
 //                                    threads calling Sift()/Sift_nointerval() through one shared context
 //                                    (SiftSetBatching) get the records a context of their own returns: frames of two
 //                                    sizes, both detectors and one frame denser than the default sizing in the mix
+//   precision <w> <h> <seed>         SiftSetPrecision: SIFT_FUSED and SIFT_SINGLE return about the features of SIFT_EXACT
+//                                    (same positions for nearly all), and SIFT_EXACT afterwards the very same records
+//                                    as before, per thread and through the shared contexts
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -73,6 +76,52 @@ int main(int argc, char **argv)
         if (SiftLastStatus() != 0 || !same_features(want, gotv))
             return fail("padded view");
         std::printf("views ok: %zu features\n", want.size());
+        return 0;
+    }
+    if (mode == "precision" && argc == 5) {
+        const int w = std::atoi(argv[2]), h = std::atoi(argv[3]);
+        Mat img = make_image(w, h, std::strtoull(argv[4], nullptr, 10));
+        auto positions_shared = [](const std::vector<Keypoint> &a, const std::vector<Keypoint> &b) {
+            size_t n = 0, j = 0; // both lists are ordered by scale; count records of a found in b near their rank
+            for (size_t i = 0; i < a.size(); i++) {
+                const size_t lo = j > 64 ? j - 64 : 0, hi = j + 64 < b.size() ? j + 64 : b.size();
+                for (size_t k = lo; k < hi; k++)
+                    if (a[i].x == b[k].x && a[i].y == b[k].y && a[i].octave == b[k].octave && a[i].interval == b[k].interval) {
+                        n++;
+                        j = k;
+                        break;
+                    }
+                j++;
+            }
+            return n;
+        };
+        for (int batch = 0; batch <= 4; batch += 4) {
+            SiftSetBatching(batch);
+            std::vector<Keypoint> exact, fused, single, again;
+            SiftSetPrecision(SIFT_EXACT);
+            Sift(img, exact, SIGMA);
+            if (SiftLastStatus() != 0 || exact.size() < 100)
+                return fail("Sift, exact");
+            SiftSetPrecision(SIFT_FUSED);
+            Sift(img, fused, SIGMA);
+            if (SiftLastStatus() != 0)
+                return fail("Sift, fused");
+            SiftSetPrecision(SIFT_SINGLE);
+            Sift(img, single, SIGMA);
+            if (SiftLastStatus() != 0)
+                return fail("Sift, single");
+            SiftSetPrecision(SIFT_EXACT);
+            Sift(img, again, SIGMA);
+            if (SiftLastStatus() != 0 || !same_features(exact, again))
+                return fail("exact after the other modes");
+            const size_t nf = positions_shared(exact, fused), ns = positions_shared(exact, single);
+            std::printf("precision (batching %d): exact %zu, fused %zu (%zu shared), single %zu (%zu shared)\n", batch,
+                        exact.size(), fused.size(), nf, single.size(), ns);
+            if (nf * 1000 < exact.size() * 990 || ns * 100 < exact.size() * 90)
+                return fail("the modes disagree beyond what their arithmetic explains");
+        }
+        SiftSetBatching(0);
+        std::printf("precision ok\n");
         return 0;
     }
     if (mode == "legacy") {
@@ -155,6 +204,6 @@ int main(int argc, char **argv)
         std::printf("shared ok: %d threads x %d calls\n", T, N);
         return 0;
     }
-    std::fprintf(stderr, "usage: %s dense w h cell out.txt | views w h seed | legacy | shared w h threads calls batch\n", argv[0]);
+    std::fprintf(stderr, "usage: %s dense w h cell out.txt | views w h seed | precision w h seed | legacy | shared w h threads calls batch\n", argv[0]);
     return 2;
 }

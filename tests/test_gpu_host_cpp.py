@@ -42,6 +42,15 @@ def test_demo_flow_matches_oracle_text(oracle, tmp_path):
     assert "match number: %d" % len(ref) in out.stdout
 
 
+def test_precision_modes_of_the_host_layer():
+    """SiftSetPrecision: the fused and single-precision pyramids give about the exact mode's features, and the exact
+    mode afterwards the same records as before, with a context per thread and with the shared contexts."""
+    exe = _need("sift_host_check")
+    out = subprocess.run([exe, "precision", "400", "300", "4242"], capture_output=True, text=True, timeout=180)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert "precision ok" in out.stdout
+
+
 def test_stage_entry_points_equal_driver():
     exe = _need("sift_stage_chain")
     out = subprocess.run([exe, "160", "120", "77"], capture_output=True, text=True, timeout=120)

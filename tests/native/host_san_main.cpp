@@ -14,6 +14,7 @@
 #include "synth_image.h"
 
 extern "C" int fake_sg_live(void);
+extern "C" int fake_sg_creates(void);
 
 #define CHECK(cond)                                                                     \
     do {                                                                                \
@@ -171,8 +172,23 @@ int main(int argc, char **argv)
         Sift(view, fa2); // appended behind what the vector holds
         Sift(view, fa2);
         CHECK(fa2.size() == 2 * fa.size() && std::memcmp(&fa2[fa.size()], fa.data(), fa.size() * sizeof(Keypoint)) == 0);
+        // another arithmetic: the shared contexts go, the next call builds new ones (the stand-in's records do not
+        // depend on the precision)
+        const int creates = fake_sg_creates();
+        SiftSetPrecision(SIFT_FUSED);
+        fa2.clear();
+        Sift(a, fa2);
+        CHECK(SiftLastStatus() == 0 && same(fa, fa2) && fake_sg_creates() > creates);
         SiftSetBatching(0);
         CHECK(fake_sg_live() == 0); // every context was handed back
+        const int creates2 = fake_sg_creates();
+        fa2.clear();
+        Sift(a, fa2); // a context of this thread, built with the fused arithmetic
+        SiftSetPrecision(SIFT_EXACT);
+        Sift(a, fa2); // ... and rebuilt for the exact one
+        CHECK(SiftLastStatus() == 0 && fa2.size() == 2 * fa.size() && fake_sg_creates() == creates2 + 2);
+        SiftReleaseContext();
+        CHECK(fake_sg_live() == 0);
     }
     std::printf("host sanitizer check ok\n");
     return 0;

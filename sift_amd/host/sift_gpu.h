@@ -177,6 +177,7 @@ struct SiftMultiGpuOptions {
     int batch = 32;                 // frames a GPU extracts per launch sequence (a 1080p frame takes 0.7 GB of pyramid)
     double sigma = SIGMA;
     bool nointerval = false;        // Sift_nointerval's detector
+    int precision = 0;              // SIFT_EXACT, SIFT_FUSED or SIFT_SINGLE (see SiftSetPrecision)
     int max_features_per_frame = 0; // 0: width * height / 40 + 4096; raised (and the shards run again) on overflow
     bool rehearsal = false;         // ranks share the GPUs present (rank r on GPU r mod G) and their sets meet in host
                                     // memory instead of RCCL, which refuses two ranks on one GPU: for trying the

@@ -79,7 +79,7 @@ struct Rank {
     void *d_img[2] = {nullptr, nullptr}, *d_out = nullptr, *d_cnt = nullptr, *d_all = nullptr, *d_all_cnt = nullptr;
     void *pinned[2] = {nullptr, nullptr};
     // shape of what is held
-    int device = -1, comm_ranks = 0, w = 0, h = 0, ch = 0, bsz = 0, per = 0, nointerval = -1, all_cnt_ranks = 0;
+    int device = -1, comm_ranks = 0, w = 0, h = 0, ch = 0, bsz = 0, per = 0, nointerval = -1, precision = -1, all_cnt_ranks = 0;
     double sigma = 0;
     size_t cap = 0, all_cap = 0, pinned_bytes = 0;
     void free_shard()
@@ -203,14 +203,16 @@ void rank_main(Shared &s, int rank)
     for (int attempt = 0; attempt < 4; attempt++) {
         s.need[(size_t)rank] = 0;
         const int ni = s.opt.nointerval ? 1 : 0;
+        const int prec = s.opt.precision == SIFT_FUSED ? SG_F64_FMA : (s.opt.precision == SIFT_SINGLE ? SG_F32 : SG_F64);
         const bool fits = r.ctx && r.w == s.w && r.h == s.h && r.ch == s.ch && r.bsz == bsz && r.per == s.per &&
-                          r.cap == cap && r.sigma == s.opt.sigma && r.nointerval == ni;
+                          r.cap == cap && r.sigma == s.opt.sigma && r.nointerval == ni && r.precision == prec;
         if (!fits) { // another shape (or a larger capacity after an overflow): everything sized from it goes
             r.free_shard();
             sg_default_params(&p);
             p.device = device;
             p.sigma = s.opt.sigma;
             p.nointerval = ni;
+            p.precision = prec;
             p.max_width = s.w;
             p.max_height = s.h;
             p.max_batch = bsz;
@@ -248,6 +250,7 @@ void rank_main(Shared &s, int rank)
                     r.per = s.per;
                     r.cap = cap;
                     r.sigma = s.opt.sigma;
+                    r.precision = prec;
                     r.nointerval = ni;
                 }
             }

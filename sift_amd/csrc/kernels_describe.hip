@@ -31,7 +31,7 @@ __device__ __forceinline__ void lds_add(double *p, double v)
 }
 
 // Histogram add in 64-bit fixed point.  The LDS pipe of a compute unit takes a 64-lane ds_add_u64 in half the time
-// of a ds_add_f64, and the descriptor kernel is bound by exactly that pipe and by the vector ALU.  A bin holds an
+// of a ds_add_f64, and the histogram adds are a sizeable part of what the descriptor kernel makes a SIMD issue.  A bin holds an
 // unsigned count of units of 2^-50.  The two factors of a contribution carry 2^-512 each on top of that unit, so their
 // product a*b (below 4 in real terms) falls into the subnormal range, where a double's bit pattern IS its value in
 // units of 2^-1074: one multiply rounds the contribution to a whole unit (to nearest, ties to even) and leaves the
@@ -45,15 +45,9 @@ constexpr double kFixWeightHalf = 0x1p-231;
 constexpr double kFixWeight = 0x1p-462;
 constexpr double kFixFrac = 0x1p-562;
 static_assert(kFixWeightHalf * kFixWeightHalf == kFixWeight && kFixWeight * kFixFrac == 0x1p-1024, "the scales meet at 2^-1024");
-__device__ __forceinline__ void lds_add_fixed(unsigned long long *p, double a, double b)
-{
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(a * b);
-    __hip_atomic_fetch_add(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 
 // LDS addresses as 32-bit integers (what the ds_ instructions take), for address arithmetic the compiler is not to
 // rearrange: a * b + c with 24-bit factors is one full-rate instruction.
-typedef __attribute__((address_space(3))) unsigned long long lds_u64_t;
 __device__ __forceinline__ unsigned int lds_address(void *p)
 {
     return (unsigned int)(size_t)(__attribute__((address_space(3))) void *)p;
@@ -64,16 +58,6 @@ __device__ __forceinline__ unsigned int mad_u24(unsigned int a, unsigned int b_u
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(b_uniform), "v"(c));
     return d;
 }
-__device__ __forceinline__ void lds_add_fixed_at(unsigned int address, double a, double b)
-{
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(a * b);
-#ifdef SG_X_NOATOM // timing experiment: the product is formed, the add is not issued
-    asm volatile("" ::"v"(bits), "v"(address));
-#else
-    __hip_atomic_fetch_add((lds_u64_t *)(size_t)address, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
-}
-
 // Two histogram adds (the two orientation bins of one cell) for the lanes of `mask`, which is a wave mask in scalar
 // registers, computed well before: the execution mask is set from it around the two adds and put back.  Setting the
 // execution mask from scalar registers costs nothing, whereas a vector compare whose result goes straight into the
@@ -84,7 +68,7 @@ template <int OFFSET>
 __device__ __forceinline__ void lds_add_fixed_pair_masked(unsigned int address, double a, double b0, double b1,
                                                           unsigned long long mask)
 {
-    const double p0 = a * b0, p1 = a * b1; // bit patterns = whole units (see lds_add_fixed)
+    const double p0 = a * b0, p1 = a * b1; // bit patterns = whole units (see above)
 #ifdef SG_X_NOATOM // timing experiment: the products are formed, the adds are not issued
     asm volatile("" ::"v"(p0), "v"(p1), "v"(address), "s"(mask));
 #else
@@ -380,7 +364,7 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
 // lane, a superset by a 1e-6 px margin, clipped to the pixels that have a gradient), the wave then writes the
 // intervals' (row, column) pairs into a queue, and takes the queued samples 64 at a time: the reference's
 // acceptance test in double, gradient, and the trilinear spread into 4x4x8 histograms with LDS atomics in 64-bit
-// fixed point (lds_add_fixed; six copies of the histograms, lane % 6, at a stride that puts them in different banks).
+// fixed point (lds_add_fixed_pair_masked; six copies of the histograms, lane % 6, at a stride that puts them in different banks).
 // So the expensive part runs with full lanes and the window's corners outside the grid are never visited.
 // Against the reference's per-sample formulas three things are algebraically regrouped (results agree to
 // ~1e-15 relative): the rotated coordinates use cos/shw and sin/shw in fused multiply-adds, the window weight
@@ -406,35 +390,6 @@ constexpr int kDescCopyStride = 16 * kDescCellBins + 2; // entries; + 2, so that
 constexpr int kDescTab = 256;      // weight table entries of the wide-window variant (one per window row/column)
 constexpr int kDescTabSmall = 128; // ... of the common variant (every radius below 64)
 constexpr int kDescPackRadius = 127; // largest radius whose (row, column) pair fits the 16-bit queue entry
-
-// Inclusive scans over the 64 lanes with data-parallel-primitive moves (no LDS): shifts by 1, 2, 4, 8 inside the rows of
-// 16 lanes, then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into the upper half.  A lane with no source keeps
-// the neutral 0.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ unsigned int dpp_or_zero(unsigned int v)
-{
-    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ unsigned int wave_scan_add(unsigned int v)
-{
-    v += dpp_or_zero<0x111, 0xf>(v); // row_shr:1
-    v += dpp_or_zero<0x112, 0xf>(v);
-    v += dpp_or_zero<0x114, 0xf>(v);
-    v += dpp_or_zero<0x118, 0xf>(v);
-    v += dpp_or_zero<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
-    v += dpp_or_zero<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ unsigned int wave_scan_max(unsigned int v)
-{
-    v = max(v, dpp_or_zero<0x111, 0xf>(v));
-    v = max(v, dpp_or_zero<0x112, 0xf>(v));
-    v = max(v, dpp_or_zero<0x114, 0xf>(v));
-    v = max(v, dpp_or_zero<0x118, 0xf>(v));
-    v = max(v, dpp_or_zero<0x142, 0xa>(v));
-    v = max(v, dpp_or_zero<0x143, 0xc>(v));
-    return v;
-}
 
 __device__ __forceinline__ double wave_sum(double v)
 {
@@ -483,7 +438,7 @@ struct DescrLds {
     double2 lut[kSinLutEntries];                 // direction table (sg_angle_sin_lut)
     double etab[BIG ? kDescTab : kDescTabSmall]; // etab[k] = E[|k - radius|], k = row or column in the window
     unsigned short queue[kDescQueue + (BIG ? 2 : 1) * kDescQueuePad]; // (the wide-window variant: 256, for the overrun of its longest row)
-    unsigned long long hist[kDescCopies * kDescCopyStride]; // units of 2^-50 (lds_add_fixed)
+    unsigned long long hist[kDescCopies * kDescCopyStride]; // units of 2^-50 (lds_add_fixed_pair_masked)
 };
 static_assert(offsetof(DescrLds<false>, hist) % 16 == 0 && offsetof(DescrLds<false>, hist) >= 5 * kDescCellBins * 8,
               "16-byte stores clear the histograms; addresses stay positive");
@@ -734,7 +689,8 @@ descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img, const 
                 ck.x = *(const __attribute__((address_space(3))) double *)(size_t)(lut_at + lut_off);
                 ck.y = *(const __attribute__((address_space(3))) double *)(size_t)(lut_at + lut_off + 8u);
 #endif
-                // (3) while that read is under way: sqrt as in sg_sqrt_sum (its seed and residual also serve the direction)
+                // (3) while that read is under way: the square root by one Newton-Raphson step on the seed (sg_math.h; the seed and
+                // the step's residual also serve the direction)
                 const double g = m2 * y, hh = 0.5 * y;
                 const double res = __builtin_fma(-hh, g, 0.5);
                 const double grad_mag = __builtin_fma(g, res, g);

@@ -85,26 +85,11 @@ __device__ __forceinline__ double sg_atan_split(double mn, double mx, const doub
 // bin weights is continuous, so a relative error of 1e-14 per sample is as good there as 1e-16 (the quantised bins sit
 // 1e-9 and more away from their truncation boundaries); these forms stop one correction step earlier than the
 // 1-ulp ones above.  They are not used where a rounding decision follows directly (orientation bins).
-
-// sqrt(x), x >= 0: v_rsq_f64 seed (about 2^-23 relative) and one coupled Newton-Raphson step: relative error below
-// 3e-14; exactly 0 for x = 0 (the seed of the clamped argument is finite).
-__device__ __forceinline__ double sg_sqrt_sum(double x)
-{
-    const double y = __builtin_amdgcn_rsq(__builtin_fmax(x, 1e-300));
-    const double g = x * y;
-    const double h = 0.5 * y;
-    const double r = __builtin_fma(-h, g, 0.5);
-    return __builtin_fma(g, r, g);
-}
-
-// n / d, d > 0: v_rcp_f64 seed and one Newton step on the reciprocal: relative error below 3e-14
-__device__ __forceinline__ double sg_div_sum(double n, double d)
-{
-    double r = __builtin_amdgcn_rcp(d);
-    const double e = __builtin_fma(-d, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return n * r;
-}
+//
+// sqrt(x), x >= 0, in that class (written out in the descriptor kernel's sample loop, which also needs its parts):
+//   y = v_rsq_f64(max(x, 1e-300))   the seed, about 2^-23 relative
+//   g = x y, h = y / 2, r = 1/2 - h g, sqrt = g + g r      one coupled Newton-Raphson step: relative error below 3e-14,
+// exactly 0 for x = 0 (the seed of the clamped argument is finite).
 
 // Direction of a gradient from its magnitude's reciprocal, with no division.  The sample loop already holds
 // y ~ 1/sqrt(dx^2+dy^2) (the v_rsq_f64 seed) and the residual r of its Newton step, so sin(theta) = mn*y for the

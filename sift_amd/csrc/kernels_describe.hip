@@ -391,6 +391,25 @@ constexpr int kDescTab = 256;      // weight table entries of the wide-window va
 constexpr int kDescTabSmall = 128; // ... of the common variant (every radius below 64)
 constexpr int kDescPackRadius = 127; // largest radius whose (row, column) pair fits the 16-bit queue entry
 
+// Inclusive sum over the 64 lanes with data-parallel-primitive moves (no LDS): shifts by 1, 2, 4, 8 inside the rows of
+// 16 lanes, then lane 15 of rows 0 and 2 into rows 1 and 3, then lane 31 into the upper half.  A lane with no source
+// takes 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned int dpp_or_zero(unsigned int v)
+{
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ unsigned int wave_scan_add(unsigned int v)
+{
+    v += dpp_or_zero<0x111, 0xf>(v); // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);
+    v += dpp_or_zero<0x114, 0xf>(v);
+    v += dpp_or_zero<0x118, 0xf>(v);
+    v += dpp_or_zero<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 __device__ __forceinline__ double wave_sum(double v)
 {
 #pragma unroll
@@ -525,17 +544,26 @@ descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img, const 
         const double Tm = 2.5 * shw + 1e-6;
         const bool c_ok = fabs(cos_ori) > 1e-9, s_ok = fabs(sin_ori) > 1e-9;
         const double inv_c = c_ok ? 1.0 / cos_ori : 0.0, inv_s = s_ok ? 1.0 / sin_ori : 0.0;
-        // row spans: lane L holds rows L, L+64, L+128, L+192 as (cnt << 8) | (lo + radius)
-        unsigned int span[4] = {0u, 0u, 0u, 0u};
+        // Row spans: lane L holds rows L, L+64, L+128, L+192 (sets 0..3; two sets when every radius < 64), each as
+        // (listed samples in the rows before it) << 16 | (its listed samples) << 8 | (its first listed column): the
+        // samples of a window are numbered row by row, at most 255 * 255 of them.
+        constexpr int kSets = BIG ? 4 : 2;
+        unsigned int span[kSets];
+        unsigned int n_total = 0;
         if (packed) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < kSets; k++) {
                 const int row = lane + 64 * k;
-                if (64 * k < W && row < W) {
-                    int lo, cnt;
-                    descr_row_span(row - radius, cos_ori, sin_ori, inv_c, inv_s, c_ok, s_ok, Tm, radius, r.x, r.y, rows,
-                                   cols, lo, cnt);
-                    span[k] = cnt > 0 ? ((unsigned int)cnt << 8) | (unsigned int)(lo + radius) : 0u;
+                span[k] = 0u;
+                if (64 * k < W) { // (uniform)
+                    int lo = 0, cnt = 0;
+                    if (row < W)
+                        descr_row_span(row - radius, cos_ori, sin_ori, inv_c, inv_s, c_ok, s_ok, Tm, radius, r.x, r.y, rows,
+                                       cols, lo, cnt);
+                    const unsigned int n = cnt > 0 ? (unsigned int)cnt : 0u;
+                    const unsigned int incl = wave_scan_add(n);
+                    span[k] = ((n_total + incl - n) << 16) | (n << 8) | ((unsigned int)(lo + radius) & 255u);
+                    n_total += (unsigned int)__builtin_amdgcn_readlane((int)incl, 63);
                 }
             }
         }
@@ -544,49 +572,69 @@ descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img, const 
         const unsigned int etab_at = lds_address(etab), lut_at = lds_address(lds.lut);
         wave_lds_fence();
 
-        int row = 0, row_used = 0; // row_used: samples of `row` that earlier rounds have taken
-        while (row < W) {
-            // ---- fill: rows, one after the other, until the queue is full (packed; a row may end in the next round),
-            // or one row's span computed on the spot ----
+        const unsigned int queue_lane = lds_address(queue + lane);
+        int row = 0;    // wide windows: the row whose samples are taken next
+        int q_base = 0; // listed windows: the number of the round's first sample
+        while (packed ? q_base < (int)n_total : row < W) {
+            // ---- fill: the next kDescQueue samples of the window (listed), or one row's span computed on the spot ----
             int count = 0, big_lo = 0;
             const int big_row = row;
             if (packed) {
-                unsigned int last_val = 0;
-#ifdef SG_X_NOFILL // timing experiment (with SG_X_NODRAIN): no queue either
-                row = W;
-#endif
-                while (row < W) {
-                    const unsigned int sv = row < 64 ? span[0] : (row < 128 ? span[1] : (row < 192 ? span[2] : span[3]));
-                    const unsigned int sp = (unsigned int)__builtin_amdgcn_readlane((int)sv, row & 63);
-                    const int cnt = (int)(sp >> 8) - row_used;
-                    const int take = min(cnt, kDescQueue - count);
-                    // a row has at most 2*radius+1 <= 255 columns (127 when every radius < 64).  Whole waves store: what
-                    // lands behind the row's last sample is overwritten by the next row or by the padding below (the
-                    // slots behind the queue take the overrun of the last row), and a store under a lane condition
-                    // would cost more than the store (see lds_add_fixed_pair_masked).
-                    const unsigned int first = (((unsigned int)row << 8) | (sp & 255u)) + (unsigned int)row_used;
-                    unsigned short *qrow = queue + count + lane;
-                    if (take > 0)
-                        qrow[0] = (unsigned short)(first + (unsigned int)lane);
+                count = min((int)n_total - q_base, kDescQueue);
+                // The rows that have samples in this round, one after the other: a row's k-th sample goes to slot
+                // (samples before the row) + k - q_base.  Whole waves store: what lands behind a row's last sample is
+                // overwritten by the next row or by the padding below (the slots behind the queue take the overrun of
+                // the last row), and a store under a lane condition would cost more than the store (see
+                // lds_add_fixed_pair_masked).  The loop runs on the scalar unit, which the 16 waves of a compute unit
+                // share: its body is kept to a dozen scalar instructions and has no branch but the rare one for rows of
+                // more than 64 samples.
+#ifndef SG_X_NOFILL
 #pragma unroll
-                    for (int u = 1; u < (BIG ? 4 : 2); u++)
-                        if (take > 64 * u) // (uniform)
-                            qrow[64 * u] = (unsigned short)(first + (unsigned int)lane + 64u * u);
-                    if (take > 0)
-                        last_val = first + (unsigned int)take - 1u;
-                    count += take;
-                    if (take < cnt) {
-                        row_used += take;
-                        break;
+                for (int k = 0; k < kSets; k++) {
+                    if (64 * k < W) { // (uniform)
+                        const unsigned int before = span[k] >> 16, n = (span[k] >> 8) & 255u;
+                        // rows of this set that end before the round, and rows that begin before its end (the prefix
+                        // sums ascend with the lane, so both are counts of a lane prefix)
+                        const int r_first = __builtin_popcountll(__builtin_amdgcn_ballot_w64(before + n <= (unsigned int)q_base));
+                        const int r_end = min(__builtin_popcountll(__builtin_amdgcn_ballot_w64(before < (unsigned int)(q_base + kDescQueue))),
+                                              min(64, W - 64 * k));
+                        // every lane works out its own row's part -- the first slot (as a byte offset) and the first
+                        // entry -- so that the loop over the rows only has to hand them to the wave
+                        const int pos = (int)before - q_base; // slot of the row's first sample (negative: it began in the round before)
+                        const int k0 = max(-pos, 0);
+                        const unsigned int row_at = 2u * (unsigned int)max(pos, 0);
+                        const unsigned int row_first = ((((unsigned int)(64 * k + lane)) << 8) | (span[k] & 255u)) + (unsigned int)k0;
+                        for (int rl = r_first; rl < r_end; rl++) {
+                            const unsigned int at = queue_lane + (unsigned int)__builtin_amdgcn_readlane((int)row_at, rl);
+                            const unsigned int first = (unsigned int)__builtin_amdgcn_readlane((int)row_first, rl) + (unsigned int)lane;
+                            *(__attribute__((address_space(3))) unsigned short *)(size_t)at = (unsigned short)first;
+                        }
+                        // rows with more than 64 samples left (few, and only in wide windows): their further stores, which
+                        // come after the stores of the rows behind them and therefore end with the row
+                        unsigned long long more = __builtin_amdgcn_ballot_w64((int)n - k0 > 64 && lane >= r_first && lane < r_end);
+                        while (more) {
+                            const int rl = __builtin_ctzll(more);
+                            more &= more - 1;
+                            const unsigned int at = queue_lane + (unsigned int)__builtin_amdgcn_readlane((int)row_at, rl);
+                            const unsigned int first = (unsigned int)__builtin_amdgcn_readlane((int)row_first, rl) + (unsigned int)lane;
+                            const int left = __builtin_amdgcn_readlane((int)n - k0, rl);
+#pragma unroll
+                            for (int u = 1; u < (BIG ? 4 : 2); u++)
+                                if (lane + 64 * u < left)
+                                    *(__attribute__((address_space(3))) unsigned short *)(size_t)(at + 128u * u) =
+                                        (unsigned short)(first + 64u * u);
+                        }
                     }
-                    row++;
-                    row_used = 0;
                 }
+#endif
+                wave_lds_fence();
                 // the slots up to the end of the last double trip, and the two trips of look-ahead behind it, repeat the last entry
+                const unsigned int last_val = queue[count - 1];
                 const int padded = ((count + 127) & ~127) + kDescQueuePad;
 #pragma unroll
                 for (int u = 0; u < 4; u++) // (lanes beyond the end write its last slot again)
                     queue[min(count + lane + 64 * u, padded - 1)] = (unsigned short)last_val;
+                q_base += kDescQueue;
                 wave_lds_fence();
             } else if (BIG) {
                 descr_row_span(row - radius, cos_ori, sin_ori, inv_c, inv_s, c_ok, s_ok, Tm, radius, r.x, r.y, rows, cols,

@@ -410,12 +410,25 @@ __device__ __forceinline__ unsigned int wave_scan_add(unsigned int v)
     return v;
 }
 
+// Sum over the 64 lanes, the same value in every lane: partial sums move between lanes as data-parallel-primitive
+// operands (an inclusive scan as in wave_scan_add: lane 63 ends with the total), which lane 63 then hands to the wave
+// through scalar registers.  No LDS round trips (six dependent ones per sum with shuffles).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1)
-        v += __shfl_xor(v, d);
-    return v;
+    v += dpp_or_zero_f64<0x111, 0xf>(v); // row_shr:1
+    v += dpp_or_zero_f64<0x112, 0xf>(v);
+    v += dpp_or_zero_f64<0x114, 0xf>(v);
+    v += dpp_or_zero_f64<0x118, 0xf>(v);
+    v += dpp_or_zero_f64<0x142, 0xa>(v); // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero_f64<0x143, 0xc>(v); // row_bcast:31 into rows 2 and 3
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
 // Columns [lo, lo+cnt) (as offsets jj from the feature) of window row i that can pass the acceptance test
@@ -604,10 +617,19 @@ descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img, const 
                         const int k0 = max(-pos, 0);
                         const unsigned int row_at = 2u * (unsigned int)max(pos, 0);
                         const unsigned int row_first = ((((unsigned int)(64 * k + lane)) << 8) | (span[k] & 255u)) + (unsigned int)k0;
-                        for (int rl = r_first; rl < r_end; rl++) {
-                            const unsigned int at = queue_lane + (unsigned int)__builtin_amdgcn_readlane((int)row_at, rl);
-                            const unsigned int first = (unsigned int)__builtin_amdgcn_readlane((int)row_first, rl) + (unsigned int)lane;
-                            *(__attribute__((address_space(3))) unsigned short *)(size_t)at = (unsigned short)first;
+                        // (four rows per pass, so that their broadcasts and stores overlap; the last pass repeats its last row)
+                        for (int rl = r_first; rl < r_end; rl += 4) {
+                            unsigned int at[4], first[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const int rj = min(rl + j, r_end - 1);
+                                at[j] = (unsigned int)__builtin_amdgcn_readlane((int)row_at, rj);
+                                first[j] = (unsigned int)__builtin_amdgcn_readlane((int)row_first, rj);
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                *(__attribute__((address_space(3))) unsigned short *)(size_t)(queue_lane + at[j]) =
+                                    (unsigned short)(first[j] + (unsigned int)lane);
                         }
                         // rows with more than 64 samples left (few, and only in wide windows): their further stores, which
                         // come after the stores of the rows behind them and therefore end with the row

@@ -89,6 +89,15 @@ __device__ __forceinline__ void lds_add_fixed_pair_masked(unsigned int address, 
 #endif
 }
 
+// A double moved between lanes as a data-parallel-primitive operand (two 32-bit moves); a lane without a source takes 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero_f64(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+
 // ---- orientation ---------------------------------------------------------------------------------------
 // One wave (a 64-thread workgroup) per keypoint.  CalculateOrientationHistogram (sift.cpp:1149-1199): the
 // lanes walk the (2r+1)^2 window and add mag*weight into 36-bin LDS histograms with double atomics.  The
@@ -251,39 +260,48 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
                 walk(std::false_type{});
         }
         wave_lds_fence();
+        // The 36 bins sit in lanes 0..35 from here on.  A bin's neighbours around the ring come from the lanes beside it
+        // by whole-wave shifts (data-parallel-primitive moves), the two ends from each other through scalar registers: the
+        // two smoothing passes, the maximum and the peak test then need no LDS round trips (they took a dozen).
         const bool binlane = lane < kOriBins;
-        double h0 = 0.0;
-        if (binlane)
-            h0 = ((hs[lane] + hs[kOriCopyStride + lane]) + hs[2 * kOriCopyStride + lane]) + hs[3 * kOriCopyStride + lane];
-        wave_lds_fence();
-        if (binlane)
-            hs[lane] = h0;
-        wave_lds_fence();
         double c = 0.0;
+        if (binlane)
+            c = ((hs[lane] + hs[kOriCopyStride + lane]) + hs[2 * kOriCopyStride + lane]) + hs[3 * kOriCopyStride + lane];
+        auto lane_value = [&](double v, int l) {
+            return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+        };
+        auto ring_prev = [&](double v) { // the value of the bin below (bin 35 for bin 0)
+            const double below = dpp_or_zero_f64<0x138, 0xf>(v); // wave_shr:1
+            const double wrap = lane_value(v, kOriBins - 1);
+            return lane == 0 ? wrap : below;
+        };
+        auto ring_next = [&](double v) { // the value of the bin above (bin 0 for bin 35)
+            const double above = dpp_or_zero_f64<0x130, 0xf>(v); // wave_shl:1
+            const double wrap = lane_value(v, 0);
+            return lane == kOriBins - 1 ? wrap : above;
+        };
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) { // ORI_SMOOTH_TIMES
-            if (binlane) {
-                double prev = hs[lane == 0 ? kOriBins - 1 : lane - 1];
-                double next = hs[lane + 1 >= kOriBins ? 0 : lane + 1];
-                c = 0.25 * prev + 0.5 * hs[lane] + 0.25 * next;
-            }
-            wave_lds_fence();
-            if (binlane)
-                hs[lane] = c;
-            wave_lds_fence();
+            const double prev = ring_prev(c), next = ring_next(c);
+            c = 0.25 * prev + 0.5 * c + 0.25 * next;
         }
-        double mx = binlane ? c : -1.0;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            double t = __shfl_xor(mx, d);
-            mx = t > mx ? t : mx;
+        // the largest bin: a running maximum towards lane 63 (0 stands in where a lane has no source: bins are >= 0)
+        double mx = binlane ? c : 0.0;
+        {
+            double t;
+            t = dpp_or_zero_f64<0x111, 0xf>(mx); mx = t > mx ? t : mx; // row_shr:1
+            t = dpp_or_zero_f64<0x112, 0xf>(mx); mx = t > mx ? t : mx;
+            t = dpp_or_zero_f64<0x114, 0xf>(mx); mx = t > mx ? t : mx;
+            t = dpp_or_zero_f64<0x118, 0xf>(mx); mx = t > mx ? t : mx;
+            t = dpp_or_zero_f64<0x142, 0xa>(mx); mx = t > mx ? t : mx; // row_bcast:15
+            t = dpp_or_zero_f64<0x143, 0xc>(mx); mx = t > mx ? t : mx; // row_bcast:31
+            mx = lane_value(mx, 63);
         }
         bool peak = false;
-        if (binlane) {
-            double l = hs[lane == 0 ? kOriBins - 1 : lane - 1];
-            double rr = hs[(lane + 1) % kOriBins];
-            double thr = mx * 0.8; // ORI_PEAK_RATIO
-            if (c > l && c > rr && c >= thr) {
+        {
+            const double l = ring_prev(c), rr = ring_next(c);
+            const double thr = mx * 0.8; // ORI_PEAK_RATIO
+            if (binlane && c > l && c > rr && c >= thr) {
                 peak = true;
                 double bin = lane + (0.5 * (l - rr) / (l - 2.0 * c + rr));
                 bin = (bin < 0) ? (bin + kOriBins) : (bin >= kOriBins ? (bin - kOriBins) : bin);
@@ -413,13 +431,6 @@ __device__ __forceinline__ unsigned int wave_scan_add(unsigned int v)
 // Sum over the 64 lanes, the same value in every lane: partial sums move between lanes as data-parallel-primitive
 // operands (an inclusive scan as in wave_scan_add: lane 63 ends with the total), which lane 63 then hands to the wave
 // through scalar registers.  No LDS round trips (six dependent ones per sum with shuffles).
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_or_zero_f64(double v)
-{
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
 __device__ __forceinline__ double wave_sum(double v)
 {
     v += dpp_or_zero_f64<0x111, 0xf>(v); // row_shr:1

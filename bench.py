@@ -14,7 +14,9 @@ ordering, 144-byte packed features).  With the defaults 4 steps x 256 frames (th
 N > 1: one process per GPU, frames sharded by rank as in the 4096-frame config (global frame f has seed 1000 + f and
 lives on rank f // 512; no data-path exchange during extraction); after every step the ranks all-gather their packed
 feature sets (sg_allgather_features of the C ABI: an all-gather-v over RCCL, overlapped with the next step's
-kernels).  Rank 0 prints one JSON line.  Outside the timed region the line also gets: a check of the last batch
+kernels).  Before a multi-rank measurement sets anything up, a trial of that exchange runs in child processes beside
+the ranks (preflight_abi_exchange); if it fails or does not return, the measured run exchanges through
+torch.distributed instead and says so (exchange, exchange_preflight).  Rank 0 prints one JSON line.  Outside the timed region the line also gets: a check of the last batch
 against the same frames run alone, single-frame latencies (1080p and 8K), and the throughput of the reference's own
 entry point Sift() through the host C++ layer.
 """
@@ -388,6 +390,108 @@ def two_batches_in_flight(args, B):
         return {"error": repr(e)}
 
 
+def preflight_child():
+    """One rank of the trial exchange, in a process of its own (`bench.py --preflight-child`).
+
+    With several ranks the C ABI's exchange (sg_comm_create, sg_allgather_features: the library's own RCCL binding)
+    meets real peers for the first time, and a collective that never returns cannot be left from inside the process
+    that entered it.  So before the measured processes allocate anything, every rank starts this program: the ranks
+    meet over gloo on a port of their own, build an RCCL communicator through the C ABI, all-gather two sets of
+    patterned records with ragged counts (a frame without features among them) and compare every gathered byte and
+    count with what the pattern says.  Exit status 0: the exchange works on this node; anything else (or no exit
+    within the parent's time limit) sends the measured run through torch.distributed's all-gather instead."""
+    import datetime
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("SIFT_BENCH_PREFLIGHT_FAIL"):  # for tests of the parents' fallback
+        sys.exit(5)
+    import torch
+    import torch.distributed as dist
+    import sift_amd
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    if world > 1:
+        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["SIFT_BENCH_PREFLIGHT_PORT"],
+                                rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+    ids = [sift_amd.api.comm_unique_id() if rank == 0 else None]
+    if world > 1:
+        dist.broadcast_object_list(ids, src=0)
+    ctx = sift_amd.SiftGPU(max_width=64, max_height=64, max_batch=1, device=dev_index)
+    comm = ctx.comm_create(ids[0], rank, world)
+    n_img, cap, words = 4, 65536, 144 // 8  # 38 MB of padded records per rank
+    ok = True
+    for trial in range(2):
+        def counts_of(r):
+            return [((r * 7919 + i * 104729 + trial * 31337 + 12345) % cap) if (r + i + trial) % 5 else 0
+                    for i in range(n_img)]
+
+        def tag(r):
+            return (r << 48) | (trial << 40)
+
+        mine = torch.arange(n_img * cap * words, dtype=torch.int64, device=dev) ^ tag(rank)
+        counts = torch.tensor(counts_of(rank), dtype=torch.int32, device=dev)
+        cap_all = world * n_img * cap
+        g = torch.full((cap_all * words,), -1, dtype=torch.int64, device=dev)
+        gc = torch.full((world * n_img,), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        first = ctx.allgather_features(comm, mine.data_ptr(), counts.data_ptr(), n_img, cap, g.data_ptr(), cap_all,
+                                       gc.data_ptr(), world)
+        ctx.sync()
+        ok = ok and gc.cpu().tolist() == [c for r in range(world) for c in counts_of(r)]
+        at = 0
+        for r in range(world):
+            ok = ok and first[r] == at
+            for i, c in enumerate(counts_of(r)):
+                want = torch.arange(i * cap * words, (i * cap + c) * words, dtype=torch.int64, device=dev) ^ tag(r)
+                ok = ok and torch.equal(g[at * words: (at + c) * words], want)
+                at += c
+        ok = ok and first[world] == at and bool((g[at * words:] == -1).all().item())
+    ctx.comm_destroy(comm)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+    sys.exit(0 if ok else 3)
+
+
+def preflight_abi_exchange(rank, world, dist, torch, dev):
+    """Runs preflight_child() beside every rank and lets the ranks agree on the outcome.  Returns a dict for the
+    bench line; ["ok"] says whether the measured run may use the C ABI's exchange."""
+    import socket
+    import subprocess
+    import tempfile
+    on_dev = dist.get_backend() == "nccl"
+    port = [None]
+    if rank == 0:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port[0] = s.getsockname()[1]
+        s.close()
+    dist.broadcast_object_list(port, src=0)
+    limit = float(os.environ.get("SIFT_BENCH_PREFLIGHT_TIMEOUT", "150"))
+    t0 = time.perf_counter()
+    why = ""
+    with tempfile.TemporaryFile(mode="w+") as err:
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preflight-child"], stdout=subprocess.DEVNULL,
+                             stderr=err, env=dict(os.environ, SIFT_BENCH_PREFLIGHT_PORT=str(port[0])))
+        try:
+            rc = p.wait(timeout=limit)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+            rc = None
+        if rc != 0:
+            err.seek(0)
+            tail = err.read().strip().splitlines()[-1:]
+            why = ("no exit within %.0f s" % limit) if rc is None else "exit status %d%s" % (rc, ": " + tail[0][-200:] if tail else "")
+    t = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return {"ok": bool(t.item()), "this_rank_ok": rc == 0, "this_rank": why or "ok", "seconds": time.perf_counter() - t0,
+            "what": "trial all-gather-v through the C ABI's RCCL binding in child processes (two rounds of patterned "
+                    "records, ragged counts, every byte compared) before the measured processes set up theirs"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -449,6 +553,14 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
+    # The exchange step goes through the C ABI (sg_allgather_features) unless SIFT_BENCH_EXCHANGE=torch, a rehearsal
+    # backend, or a failed trial of it (preflight_abi_exchange) sends it through torch.distributed.
+    use_abi = world == 1 or (dist.get_backend() == "nccl" and os.environ.get("SIFT_BENCH_EXCHANGE", "abi") != "torch")
+    preflight = None
+    pf_mode = os.environ.get("SIFT_BENCH_PREFLIGHT", "1")
+    if world > 1 and pf_mode != "0" and (use_abi or pf_mode == "force"):
+        preflight = preflight_abi_exchange(rank, world, dist, torch, dev)
+        use_abi = use_abi and preflight["ok"]
 
     W, H, B, K, WU = args.width, args.height, args.batch, args.steps, args.warmup
     if args.pool <= 0:
@@ -511,7 +623,7 @@ def main():
     # instead of sitting until the caller's time limit: SIFT_BENCH_EXCHANGE=torch then takes the same exchange through
     # torch.distributed instead.
     watchdog = None
-    if world > 1 and dist.get_backend() == "nccl" and os.environ.get("SIFT_BENCH_EXCHANGE", "abi") != "torch":
+    if world > 1 and use_abi:
         import threading
 
         def stuck():
@@ -532,7 +644,7 @@ def main():
         cap_all = world * B * cap
         g_outs = [torch.empty(cap_all * 144, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
         g_cnts = [torch.zeros(world * B, dtype=torch.int32, device=dev) for _ in range(nbuf)]
-        if world == 1 or (dist.get_backend() == "nccl" and os.environ.get("SIFT_BENCH_EXCHANGE", "abi") != "torch"):
+        if use_abi:
             # Every rank first checks on its own that the library can bind RCCL, and the ranks agree on the outcome
             # before any of them enters the collective set-up: a rank that cannot must not leave the others waiting.
             why = ""
@@ -570,7 +682,9 @@ def main():
                 exchange = ("torch.distributed all-gather-v over %s (RCCL through the C ABI was not usable on every "
                             "rank%s)" % (dist.get_backend(), ": " + why if why else ""))
         elif world > 1 and dist.get_backend() == "nccl":
-            exchange = "torch.distributed all-gather-v over nccl (SIFT_BENCH_EXCHANGE=torch)"
+            exchange = "torch.distributed all-gather-v over nccl (%s)" % (
+                "the trial of the C ABI's exchange failed: see exchange_preflight" if preflight is not None
+                and not preflight["ok"] else "SIFT_BENCH_EXCHANGE=torch")
         else:
             exchange = "torch.distributed all-gather-v (%s rehearsal)" % dist.get_backend()
     gathered_total = [0] * nbuf   # features in the gathered buffer b
@@ -919,7 +1033,8 @@ def main():
             valu_roofline("descr_k<double,false>", work[0], stage_ms.get("descr", 0.0) / K) if esize == 8 else None,
             valu_roofline("orient_k<double,false>", work[1], stage_ms.get("orient", 0.0) / K) if esize == 8 else None) if r],
         "batch_check": verify, "latency_ms": latency, "host_api": host_api,
-        "two_batches_in_flight": overlap, "f64_fma": f64_fma, "exchange": exchange, "exchange_check": exchange_check,
+        "two_batches_in_flight": overlap, "f64_fma": f64_fma, "exchange": exchange, "exchange_preflight": preflight,
+        "exchange_check": exchange_check,
         "features_last_step": int(feat_counts.astype(np.int64).sum()), "features_gathered_last_step": gathered_last,
         "stage_ms_per_step": {k: v / K for k, v in stage_ms.items() if v > 0},
         "blur_kernels": blur, "detect_kernel": detect,
@@ -932,4 +1047,6 @@ def main():
 
 
 if __name__ == "__main__":
+    if "--preflight-child" in sys.argv[1:]:
+        preflight_child()
     main()

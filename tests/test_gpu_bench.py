@@ -53,7 +53,10 @@ def test_bench_two_ranks_rehearsal_checks_the_exchange():
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, SIFT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    # SIFT_BENCH_PREFLIGHT=force: the trial of the C ABI's exchange runs although the backend is gloo; its children
+    # cannot build an RCCL communicator of two ranks on one device, so the parents must agree on the fallback.
+    env = dict(os.environ, SIFT_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", SIFT_BENCH_PREFLIGHT="force",
+               SIFT_BENCH_PREFLIGHT_TIMEOUT="90")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2",
            "--warmup", "1", "--batch", "3", "--pool", "6", "--width", "320", "--height", "240", "--cap", "4096",
@@ -62,6 +65,20 @@ def test_bench_two_ranks_rehearsal_checks_the_exchange():
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and "gloo" in line["exchange"]
+    assert line["exchange_preflight"]["ok"] is False and line["exchange_preflight"]["this_rank"] != "ok"
     chk = line["exchange_check"]
     assert chk["ok"] is True and chk["ranks"] == 2 and chk["checksum_equal"] and chk["counts_equal"] and chk["own_slot_equal"]
     assert chk["features_gathered"] == line["features_gathered_last_step"] > 2 * 3 * 300
+
+
+@pytest.mark.gpu
+def test_exchange_preflight_child_world_of_one():
+    """The trial exchange bench.py runs beside every rank before a multi-rank measurement, here as a world of one:
+    communicator through the C ABI's RCCL binding, two all-gathers of patterned records, every byte compared."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight-child"], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight-child"], capture_output=True,
+                       text=True, timeout=300, cwd=ROOT, env=dict(env, SIFT_BENCH_PREFLIGHT_FAIL="1"))
+    assert r.returncode == 5

@@ -412,14 +412,26 @@ def preflight_child():
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    def mark(what):  # the parent reports the last line when the child fails or does not return
+        sys.stderr.write("preflight rank %d: %s\n" % (rank, what))
+        sys.stderr.flush()
+
+    mark("started on device %d" % dev_index)
     if world > 1:
-        dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%s" % os.environ["SIFT_BENCH_PREFLIGHT_PORT"],
-                                rank=rank, world_size=world, timeout=datetime.timedelta(seconds=90))
+        # a store of the children's own (under torch.distributed.run the environment tells a tcp:// rendezvous to look
+        # for the launcher's store instead of starting one)
+        store = dist.TCPStore("127.0.0.1", int(os.environ["SIFT_BENCH_PREFLIGHT_PORT"]), world, rank == 0,
+                              timeout=datetime.timedelta(seconds=90))
+        dist.init_process_group("gloo", store=store, rank=rank, world_size=world,
+                                timeout=datetime.timedelta(seconds=90))
+    mark("ranks met over gloo")
     ids = [sift_amd.api.comm_unique_id() if rank == 0 else None]
     if world > 1:
         dist.broadcast_object_list(ids, src=0)
     ctx = sift_amd.SiftGPU(max_width=64, max_height=64, max_batch=1, device=dev_index)
+    mark("entering sg_comm_create")
     comm = ctx.comm_create(ids[0], rank, world)
+    mark("communicator built")
     n_img, cap, words = 4, 65536, 144 // 8  # 38 MB of padded records per rank
     ok = True
     for trial in range(2):
@@ -436,9 +448,11 @@ def preflight_child():
         g = torch.full((cap_all * words,), -1, dtype=torch.int64, device=dev)
         gc = torch.full((world * n_img,), -1, dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
+        mark("entering sg_allgather_features, round %d" % trial)
         first = ctx.allgather_features(comm, mine.data_ptr(), counts.data_ptr(), n_img, cap, g.data_ptr(), cap_all,
                                        gc.data_ptr(), world)
         ctx.sync()
+        mark("gathered, round %d" % trial)
         ok = ok and gc.cpu().tolist() == [c for r in range(world) for c in counts_of(r)]
         at = 0
         for r in range(world):
@@ -452,6 +466,7 @@ def preflight_child():
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
+    mark("all gathered bytes and counts as expected" if ok else "gathered bytes or counts differ from the pattern")
     sys.exit(0 if ok else 3)
 
 
@@ -474,7 +489,8 @@ def preflight_abi_exchange(rank, world, dist, torch, dev):
     why = ""
     with tempfile.TemporaryFile(mode="w+") as err:
         p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preflight-child"], stdout=subprocess.DEVNULL,
-                             stderr=err, env=dict(os.environ, SIFT_BENCH_PREFLIGHT_PORT=str(port[0])))
+                             stderr=err, env=dict({k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")},
+                                                  SIFT_BENCH_PREFLIGHT_PORT=str(port[0])))
         try:
             rc = p.wait(timeout=limit)
         except subprocess.TimeoutExpired:
@@ -483,8 +499,11 @@ def preflight_abi_exchange(rank, world, dist, torch, dev):
             rc = None
         if rc != 0:
             err.seek(0)
-            tail = err.read().strip().splitlines()[-1:]
-            why = ("no exit within %.0f s" % limit) if rc is None else "exit status %d%s" % (rc, ": " + tail[0][-200:] if tail else "")
+            lines = err.read().strip().splitlines()
+            marks = [ln for ln in lines if ln.startswith("preflight rank")]
+            errs = [ln for ln in lines if not ln.startswith(("preflight rank", "frame #", " ", "\t"))]
+            why = (("no exit within %.0f s" % limit) if rc is None else "exit status %d" % rc) + \
+                ("; got as far as: " + marks[-1][-120:] if marks else "") + ("; " + errs[-1][-200:] if errs else "")
     t = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MIN)
     return {"ok": bool(t.item()), "this_rank_ok": rc == 0, "this_rank": why or "ok", "seconds": time.perf_counter() - t0,

@@ -128,8 +128,8 @@ template <typename T, bool BIG>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SG_ORI_WPE, SG_ORI_WPE))) void
 orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsigned int *__restrict__ kp_src,
          size_t src_img, const unsigned int *__restrict__ kp_count, double *__restrict__ ori_tmp, size_t ori_img,
-         unsigned long long *__restrict__ peak_words, size_t pw_img, unsigned int *__restrict__ chunk_sums,
-         size_t chunks_img, unsigned int cap, unsigned long long *__restrict__ counters)
+         unsigned long long *__restrict__ peak_words, size_t pw_img, unsigned int cap,
+         unsigned long long *__restrict__ trip_slots)
 {
     __shared__ double hist[kOriCopies * kOriCopyStride];
     __shared__ double E[kOriTab];
@@ -308,16 +308,16 @@ orient_k(OctaveTab tab, const KpRec *__restrict__ kp, size_t kp_img, const unsig
                 ori_tmp[(size_t)b * ori_img + (size_t)j * kOriBins + lane] = ((PI2 * bin) / kOriBins) - SG_PI;
             }
         }
+        // (the peaks are counted per chunk of keypoints by a launch of their own, launch_chunk_popc: counting here
+        // would be one atomic add per keypoint on a word that a thousand keypoints share)
         unsigned long long m = __ballot(peak);
-        if (lane == 0) {
+        if (lane == 0)
             peak_words[(size_t)b * pw_img + j] = m;
-            if (m)
-                atomicAdd(&chunk_sums[(size_t)b * chunks_img + j / kChunkWords], (unsigned int)__popcll(m));
-        }
         wave_lds_fence(); // the histograms are cleared for the next keypoint
     }
     if (lane == 0 && trips)
-        atomicAdd(&counters[(size_t)b * 8 + 6], (unsigned long long)trips);
+        atomicAdd(&trip_slots[(size_t)b * kTripWordsPerImage + (size_t)(kTripSlots + blockIdx.x % kTripSlots) * kTripStride],
+                  (unsigned long long)trips);
 }
 
 // One-wave workgroups per image for the kernels that walk a list of keypoints or features with a grid-stride loop.
@@ -343,8 +343,8 @@ static unsigned int feature_blocks(unsigned int cap, int B, unsigned int waves_p
 void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
                    size_t src_img_stride, const unsigned int *kp_count, double *ori_tmp, size_t ori_img_stride,
                    unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
-                   size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec,
-                   unsigned long long *counters, hipStream_t s)
+                   size_t chunks_img_stride, int n_chunks, unsigned int cap, int max_radius, int B, int prec,
+                   unsigned long long *trip_slots, hipStream_t s)
 {
     // Short lists (a frame alone, a small batch): one resident generation of waves (20 per compute unit) -- a keypoint
     // list that fills the chip only a few times over is finished sooner by waves that stay and take several keypoints
@@ -360,7 +360,7 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
     const bool big = max_radius >= kOriTab;
 #define SG_ORI_LAUNCH(TT, BB)                                                                                         \
     orient_k<TT, BB><<<g, 64, 0, s>>>(tab, kp, kp_img_stride, kp_src, src_img_stride, kp_count, ori_tmp, ori_img_stride, \
-                                      peak_words, pw_img_stride, chunk_sums, chunks_img_stride, cap, counters)
+                                      peak_words, pw_img_stride, cap, trip_slots)
     if (prec == SG_F64) {
         if (big)
             SG_ORI_LAUNCH(double, true);
@@ -373,6 +373,9 @@ void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, 
             SG_ORI_LAUNCH(float, false);
     }
 #undef SG_ORI_LAUNCH
+    // peaks per chunk of keypoints (one word per keypoint; words beyond the list are stale and not counted)
+    launch_chunk_popc(peak_words, pw_img_stride, (unsigned int)pw_img_stride, kp_count, 1, chunk_sums, chunks_img_stride,
+                      n_chunks, B, s);
 }
 
 // ---- descriptors -----------------------------------------------------------------------------------------
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(64)
 __attribute__((amdgpu_waves_per_eu(BIG ? 4 : SG_DESCR_WPE, BIG ? 4 : SG_DESCR_WPE))) void // (the wide tables leave room for fewer)
 descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img, const unsigned int *__restrict__ feat_count,
         uint8_t *__restrict__ desc, size_t desc_img, double *__restrict__ prequant, size_t pq_img, unsigned int cap,
-        unsigned long long *__restrict__ counters)
+        unsigned long long *__restrict__ trip_slots)
 {
     __shared__ __align__(16) DescrLds<BIG> lds;
     const int lane = threadIdx.x;
@@ -874,12 +877,13 @@ descr_k(OctaveTab tab, const FeatRec *__restrict__ frec, size_t frec_img, const 
         wave_lds_fence(); // the histograms are cleared for the next feature
     }
     if (lane == 0 && trips)
-        atomicAdd(&counters[(size_t)b * 8 + 5], (unsigned long long)trips);
+        atomicAdd(&trip_slots[(size_t)b * kTripWordsPerImage + (size_t)(blockIdx.x % kTripSlots) * kTripStride],
+                  (unsigned long long)trips);
 }
 
 void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_stride, const unsigned int *feat_count,
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
-                  int max_radius, int B, int prec, unsigned long long *counters, hipStream_t s)
+                  int max_radius, int B, int prec, unsigned long long *trip_slots, hipStream_t s)
 {
     unsigned int waves = feature_blocks(cap, B, 384, 384, env().descr_waves);
     // about four features per wave at least (the capacity is about two and a half times a natural image's count): with
@@ -901,7 +905,7 @@ void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_str
         big = big || (size_t)tab.pitch[o] * (prec == SG_F64 ? 8u : 4u) >= ((size_t)1 << 24);
 #define SG_DESCR_LAUNCH(TT, BB)                                                                                       \
     descr_k<TT, BB><<<g, 64, 0, s>>>(tab, frec, frec_img_stride, feat_count, desc, desc_img_stride, prequant,         \
-                                     pq_img_stride, cap, counters)
+                                     pq_img_stride, cap, trip_slots)
     if (prec == SG_F64) {
         if (big)
             SG_DESCR_LAUNCH(double, true);

@@ -638,6 +638,50 @@ void launch_expand(const unsigned long long *words, size_t words_img_stride, uns
     expand_k<<<g, 256, 0, s>>>(words, words_img_stride, n_words, dyn_items, items_per_word, chunk_offs, chunks_img_stride, out, out_img_stride, cap);
 }
 
+// Per-chunk popcounts of a bitmap whose producer does not count (orient_k: one word per keypoint).  The producer's own
+// count would be one atomic add per keypoint on a handful of words -- all keypoints of a chunk of 1024 add to the
+// same word -- and adds to one word are served one after the other by the memory side (about 90 per microsecond): a
+// frame alone, whose 18 000 keypoints share 18 words, spent two thirds of the orientation kernel's time in that queue.
+// Words at or beyond ceil(items / items_per_word) hold stale bits and are not counted (as in expand_k).
+__global__ __launch_bounds__(256) void chunk_popc_k(const unsigned long long *words, size_t words_img, unsigned int n_words,
+                                                    const unsigned int *dyn_items, unsigned int items_per_word,
+                                                    unsigned int *chunk_sums, size_t chunks_img)
+{
+    __shared__ unsigned int wsum[4];
+    const int b = blockIdx.y;
+    const unsigned int chunk = blockIdx.x;
+    const unsigned long long *w = words + (size_t)b * words_img;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (dyn_items) {
+        unsigned int nw = (dyn_items[b] + items_per_word - 1u) / items_per_word;
+        n_words = nw < n_words ? nw : n_words;
+    }
+    const unsigned int w0 = chunk * kChunkWords + threadIdx.x * 4;
+    unsigned int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (w0 + q < n_words)
+            cnt += __popcll(w[w0 + q]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        cnt += __shfl_xor(cnt, d);
+    if (lane == 0)
+        wsum[wave] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        chunk_sums[(size_t)b * chunks_img + chunk] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+void launch_chunk_popc(const unsigned long long *words, size_t words_img_stride, unsigned int n_words,
+                       const unsigned int *dyn_items, unsigned int items_per_word, unsigned int *chunk_sums,
+                       size_t chunks_img_stride, int n_chunks, int B, hipStream_t s)
+{
+    if (n_chunks < 1)
+        return;
+    dim3 g((unsigned int)n_chunks, B);
+    chunk_popc_k<<<g, 256, 0, s>>>(words, words_img_stride, n_words, dyn_items, items_per_word, chunk_sums, chunks_img_stride);
+}
+
 // ---- refinement ------------------------------------------------------------------------------------------
 // InterploationExtremum, GetOffsetX, Hessian3D, DerivativeOf3D, Inverse3D, GetFabsDx, passEdgeResponse
 // (reference sift/sift.cpp:600-910), then CalculateScale and HalfFeatures (sift.cpp:1065-1096).

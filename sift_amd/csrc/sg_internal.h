@@ -18,6 +18,11 @@ constexpr int kMaxAnyTaps = 1024; // widest kernel the any-radius blur takes
 constexpr int kBorder = 5;        // IMG_BORDER, sift.h:58
 constexpr int kChunkWords = 1024; // bitmap words per compaction chunk
 constexpr int kOriBins = 36;
+// Trip counts of the histogram kernels (diagnostics: sg_read_work_counters) are added into kTripSlots words per image
+// and kernel, 64 bytes apart, the slot chosen by the workgroup's number: a launch's waves all finish at about the same
+// time, and their adds to one word would queue up at the memory side behind each other (a frame alone: 5 000 adds, 40 us).
+constexpr int kTripSlots = 64, kTripStride = 8; // slots per (image, kernel); 64-bit words from slot to slot
+constexpr size_t kTripWordsPerImage = 2 * (size_t)kTripSlots * kTripStride; // [0]: descriptors, [1]: orientation
 constexpr int kRankBuckets = 16384; // 16 binades x 1024 mantissa steps of the scale key
 
 // Debug / comparison switches, read from the environment once per process (first sg_create) and never on a launch path:
@@ -147,6 +152,10 @@ int launch_detect(const OctaveTab &tab, int B, unsigned long long *words, size_t
 void launch_scan(unsigned int *chunk_sums, size_t chunks_img_stride, int n_chunks, unsigned int *totals,
                  unsigned int cap, unsigned int *overflow, int B, hipStream_t s);
 // expand set bits of words (n_words per image) into out[b][pos] = word*64 + bit, ordered
+// per-chunk popcounts of a bitmap (n_chunks values per image), for producers that leave the counting to this launch
+void launch_chunk_popc(const unsigned long long *words, size_t words_img_stride, unsigned int n_words,
+                       const unsigned int *dyn_items, unsigned int items_per_word, unsigned int *chunk_sums,
+                       size_t chunks_img_stride, int n_chunks, int B, hipStream_t s);
 void launch_expand(const unsigned long long *words, size_t words_img_stride, unsigned int n_words,
                    const unsigned int *dyn_items, unsigned int items_per_word, const unsigned int *chunk_offs,
                    size_t chunks_img_stride, unsigned int *out,
@@ -161,8 +170,8 @@ void launch_refine(const OctaveTab &tab, const unsigned int *cand, size_t cand_i
 void launch_orient(const OctaveTab &tab, const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src,
                    size_t src_img_stride, const unsigned int *kp_count, double *ori_tmp, size_t ori_img_stride,
                    unsigned long long *peak_words, size_t pw_img_stride, unsigned int *chunk_sums,
-                   size_t chunks_img_stride, unsigned int cap, int max_radius, int B, int prec,
-                   unsigned long long *counters, hipStream_t s);
+                   size_t chunks_img_stride, int n_chunks, unsigned int cap, int max_radius, int B, int prec,
+                   unsigned long long *trip_slots, hipStream_t s);
 // gathers FeatRec[f] (and fscale[f]) from feat_src -> kp_src -> kp / ori_tmp
 void launch_feat_gather(const KpRec *kp, size_t kp_img_stride, const unsigned int *kp_src, size_t src_img_stride,
                         const unsigned int *feat_src, size_t fsrc_img_stride, const unsigned int *feat_count,
@@ -171,7 +180,7 @@ void launch_feat_gather(const KpRec *kp, size_t kp_img_stride, const unsigned in
 // max_radius: an upper bound of the features' window radii (selects the kernel variant for very wide windows)
 void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_stride, const unsigned int *feat_count,
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
-                  int max_radius, int B, int prec, unsigned long long *counters, hipStream_t s);
+                  int max_radius, int B, int prec, unsigned long long *trip_slots, hipStream_t s);
 // bwork: [B][2][kRankBuckets] scratch, blist: [B][cap] scratch, scratch_totals: [B], overflow_dummy: [1]
 void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
                  size_t rank_img_stride, unsigned int *bwork, unsigned int *blist, unsigned int *scratch_totals,

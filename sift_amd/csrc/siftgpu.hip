@@ -161,6 +161,7 @@ struct sg_ctx {
     uint8_t *d_desc = nullptr;
     unsigned int *d_counts = nullptr; // [3][B]: candidates, keypoints, features
     unsigned long long *d_ctr = nullptr; // [B][8]
+    unsigned long long *d_trips = nullptr; // [B][kTripWordsPerImage]: trip counts of the histogram kernels, in slots
     unsigned int *d_overflow = nullptr;  // [4]: candidates, keypoints, features, output; sticky until read
     unsigned int last_ov[4] = {0, 0, 0, 0}; // the counts of the last reported overflow (sg_required_features)
     void *d_out = nullptr;
@@ -458,8 +459,8 @@ static void orient_phase(sg_ctx *c, const OctaveTab &tab, int B, int max_radius)
     {
         StageScope sc(c, SG_ST_ORIENT);
         launch_orient(tab, c->d_kp, c->cand_cap, c->d_kpsrc, c->feat_cap, n_kp, c->d_ori, (size_t)c->feat_cap * kOriBins,
-                      c->d_pwords, c->pwords_img, ch3, c->chunks_total, c->feat_cap, max_radius, B, c->prm.precision,
-                      c->d_ctr, s);
+                      c->d_pwords, c->pwords_img, ch3, c->chunks_total, (int)c->chunks3, c->feat_cap, max_radius, B,
+                      c->prm.precision, c->d_trips, s);
     }
     {
         StageScope sc(c, SG_ST_COMPACT, 2);
@@ -505,7 +506,7 @@ static void descr_phase(sg_ctx *c, const OctaveTab &tab, int B, int max_radius)
                            (size_t)c->feat_cap * kOriBins, c->d_frec, c->feat_cap, c->d_fscale, c->feat_cap,
                            c->feat_cap, B, s);
         launch_descr(tab, c->d_frec, c->feat_cap, n_feat, c->d_desc, (size_t)c->feat_cap * 128, c->d_pq,
-                     (size_t)c->feat_cap * 128, c->feat_cap, max_radius, B, c->prm.precision, c->d_ctr, s);
+                     (size_t)c->feat_cap * 128, c->feat_cap, max_radius, B, c->prm.precision, c->d_trips, s);
     }
 }
 
@@ -1027,11 +1028,13 @@ int sg_create(const sg_params *p_in, sg_ctx **out)
     ALLOC(c->d_pwords, sizeof(unsigned long long) * c->pwords_img * B);
     {
         const size_t ctr_b = sizeof(unsigned long long) * 8 * B, cnt_b = (sizeof(unsigned int) * 3 * B + 15) & ~(size_t)15;
-        c->zero_bytes = ctr_b + cnt_b + sizeof(unsigned int) * c->chunks_total * B;
+        const size_t trips_b = sizeof(unsigned long long) * kTripWordsPerImage * B;
+        c->zero_bytes = ctr_b + trips_b + cnt_b + sizeof(unsigned int) * c->chunks_total * B;
         ALLOC(c->d_zero, c->zero_bytes);
         c->d_ctr = (unsigned long long *)c->d_zero;
-        c->d_counts = (unsigned int *)((char *)c->d_zero + ctr_b);
-        c->d_chunks = (unsigned int *)((char *)c->d_zero + ctr_b + cnt_b);
+        c->d_trips = (unsigned long long *)((char *)c->d_zero + ctr_b);
+        c->d_counts = (unsigned int *)((char *)c->d_zero + ctr_b + trips_b);
+        c->d_chunks = (unsigned int *)((char *)c->d_zero + ctr_b + trips_b + cnt_b);
     }
     ALLOC(c->d_cand, sizeof(unsigned int) * (size_t)c->cand_cap * B);
     ALLOC(c->d_kp, sizeof(KpRec) * (size_t)c->cand_cap * B);
@@ -1394,14 +1397,15 @@ int sg_read_work_counters(sg_ctx *c, int n_img, unsigned long long *descr_trips,
     if (!c || n_img < 1 || n_img > c->B)
         return SG_E_INVALID;
     (void)hipSetDevice(c->prm.device);
-    std::vector<unsigned long long> v((size_t)8 * n_img);
-    HIPCHK(c, hipMemcpyAsync(v.data(), c->d_ctr, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost, c->stream));
+    std::vector<unsigned long long> v(kTripWordsPerImage * n_img);
+    HIPCHK(c, hipMemcpyAsync(v.data(), c->d_trips, sizeof(unsigned long long) * v.size(), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     unsigned long long d = 0, o = 0;
-    for (int i = 0; i < n_img; i++) {
-        d += v[(size_t)8 * i + 5];
-        o += v[(size_t)8 * i + 6];
-    }
+    for (int i = 0; i < n_img; i++)
+        for (int k = 0; k < kTripSlots; k++) {
+            d += v[kTripWordsPerImage * i + (size_t)k * kTripStride];
+            o += v[kTripWordsPerImage * i + (size_t)(kTripSlots + k) * kTripStride];
+        }
     if (descr_trips)
         *descr_trips = d;
     if (orient_trips)

@@ -547,6 +547,40 @@ __global__ __launch_bounds__(1024) void scan_k(unsigned int *sums, size_t img_st
     if (threadIdx.x == 0)
         carry_s = 0;
     __syncthreads();
+    if (n >= 4096 && n % 4096 == 0 && n <= 64 * 1024) {
+        // Long inputs (the 16 384 scale buckets of the ordering step): every thread takes n / 1024 consecutive values,
+        // so the block synchronises once instead of four times per 1024 values.
+        const int per = n >> 10; // 4 .. 64, a multiple of 4
+        unsigned int *mine = a + (size_t)threadIdx.x * per;
+        unsigned int sum = 0;
+        for (int k = 0; k < per; k += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(mine + k);
+            sum += v.x + v.y + v.z + v.w;
+        }
+        const unsigned int inc = wave_incl_scan(sum, lane);
+        if (lane == 63)
+            wsum[wave] = inc;
+        __syncthreads();
+        unsigned int run = inc - sum;
+        for (int w = 0; w < wave; w++)
+            run += wsum[w];
+        for (int k = 0; k < per; k += 4) {
+            uint4 v = *reinterpret_cast<const uint4 *>(mine + k);
+            uint4 o;
+            o.x = run;
+            o.y = o.x + v.x;
+            o.z = o.y + v.y;
+            o.w = o.z + v.z;
+            run = o.w + v.w;
+            *reinterpret_cast<uint4 *>(mine + k) = o;
+        }
+        if (threadIdx.x == 1023) {
+            totals[blockIdx.x] = run < cap ? run : cap;
+            if (run > cap)
+                atomicMax(overflow, run);
+        }
+        return;
+    }
     for (int base = 0; base < n; base += 1024) {
         int i = base + threadIdx.x;
         unsigned int v = i < n ? a[i] : 0;
@@ -627,14 +661,64 @@ __global__ __launch_bounds__(256) void expand_k(const unsigned long long *words,
     }
 }
 
+// The same expansion for a bitmap in which most bits are set (the survivors of the refinement: one bit per candidate,
+// nearly half of them set).  There a short list sits in a few hundred words, which expand_k would hand to one or two
+// workgroups whose threads each walk their own words bit by bit (a frame alone: 20 us in a single workgroup).  Here a
+// wave takes 64 consecutive words of a chunk, and the lanes are the bits: word k's set bits are stored by the lanes that
+// hold them, at the word's offset plus the number of set bits below the lane's.  Same output order.
+__global__ __launch_bounds__(64) void expand_dense_k(const unsigned long long *words, size_t words_img, unsigned int n_words,
+                                                     const unsigned int *dyn_items, unsigned int items_per_word,
+                                                     const unsigned int *chunk_offs, size_t chunks_img, unsigned int *out,
+                                                     size_t out_img, unsigned int cap)
+{
+    const int b = blockIdx.y;
+    const unsigned int chunk = blockIdx.x / (kChunkWords / 64), part = blockIdx.x % (kChunkWords / 64);
+    const unsigned long long *w = words + (size_t)b * words_img;
+    const unsigned int lane = threadIdx.x;
+    if (dyn_items) {
+        unsigned int nw = (dyn_items[b] + items_per_word - 1u) / items_per_word;
+        n_words = nw < n_words ? nw : n_words;
+    }
+    const unsigned int w_first = chunk * kChunkWords + part * 64u;
+    if (w_first >= n_words)
+        return;
+    // set bits of the chunk's words in front of this wave's
+    unsigned int before = 0;
+    for (unsigned int g = 0; g < part; g++)
+        before += (unsigned int)__popcll(w[chunk * kChunkWords + g * 64u + lane]); // (all below w_first < n_words)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        before += __shfl_xor(before, d);
+    const unsigned long long mine = w_first + lane < n_words ? w[w_first + lane] : 0ull;
+    const unsigned int cnt = (unsigned int)__popcll(mine);
+    const unsigned int start = chunk_offs[(size_t)b * chunks_img + chunk] + before + wave_incl_scan(cnt, (int)lane) - cnt;
+    unsigned int *o = out + (size_t)b * out_img;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int k = 0; k < 64; k++) {
+        const unsigned long long m = __shfl(mine, k);
+        if (m == 0)
+            continue; // wave-uniform
+        const unsigned int p = __shfl(start, k) + (unsigned int)__popcll(m & below);
+        if (((m >> lane) & 1ull) && p < cap)
+            o[p] = (w_first + (unsigned int)k) * 64u + lane;
+    }
+}
+
 void launch_expand(const unsigned long long *words, size_t words_img_stride, unsigned int n_words,
                    const unsigned int *dyn_items, unsigned int items_per_word, const unsigned int *chunk_offs,
                    size_t chunks_img_stride, unsigned int *out,
-                   size_t out_img_stride, unsigned int cap, int B, hipStream_t s)
+                   size_t out_img_stride, unsigned int cap, int B, hipStream_t s, bool dense)
 {
     if (n_words == 0)
         return;
-    dim3 g((n_words + kChunkWords - 1) / kChunkWords, B);
+    const unsigned int chunks = (n_words + kChunkWords - 1) / kChunkWords;
+    if (dense) {
+        dim3 g(chunks * (kChunkWords / 64), B);
+        expand_dense_k<<<g, 64, 0, s>>>(words, words_img_stride, n_words, dyn_items, items_per_word, chunk_offs,
+                                        chunks_img_stride, out, out_img_stride, cap);
+        return;
+    }
+    dim3 g(chunks, B);
     expand_k<<<g, 256, 0, s>>>(words, words_img_stride, n_words, dyn_items, items_per_word, chunk_offs, chunks_img_stride, out, out_img_stride, cap);
 }
 

@@ -159,7 +159,7 @@ void launch_chunk_popc(const unsigned long long *words, size_t words_img_stride,
 void launch_expand(const unsigned long long *words, size_t words_img_stride, unsigned int n_words,
                    const unsigned int *dyn_items, unsigned int items_per_word, const unsigned int *chunk_offs,
                    size_t chunks_img_stride, unsigned int *out,
-                   size_t out_img_stride, unsigned int cap, int B, hipStream_t s);
+                   size_t out_img_stride, unsigned int cap, int B, hipStream_t s, bool dense = false);
 void launch_refine(const OctaveTab &tab, const unsigned int *cand, size_t cand_img_stride,
                    const unsigned int *cand_count, KpRec *kp, size_t kp_img_stride,
                    unsigned long long *valid_words, size_t vw_img_stride, unsigned int *chunk_sums,

@@ -447,7 +447,7 @@ static void detect_phase(sg_ctx *c, const OctaveTab &tab, unsigned int n_words, 
         StageScope sc(c, SG_ST_COMPACT, 2);
         launch_scan(ch2, c->chunks_total, (int)c->chunks2, n_kp, c->feat_cap, c->d_overflow + 1, B, s);
         launch_expand(c->d_vwords, c->vwords_img, (unsigned int)c->vwords_img, n_cand, 64, ch2, c->chunks_total,
-                      c->d_kpsrc, c->feat_cap, c->feat_cap, B, s);
+                      c->d_kpsrc, c->feat_cap, c->feat_cap, B, s, true); // nearly half of the candidates survive
     }
 }
 

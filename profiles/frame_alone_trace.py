@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One 1080p frame alone through the device-pointer API, a few dozen times: the program whose kernel trace
 (rocprofv3 --kernel-trace) shows the dependent-launch chain of a single frame.
-    python profiles/frame_alone_trace.py run [W H] [n]        the workload (put it behind `rocprofv3 ... --`)
+    python profiles/frame_alone_trace.py run [W H] [n] [B]    the workload (put it behind `rocprofv3 ... --`); B frames per call
     python profiles/frame_alone_trace.py read <kernel_trace.csv>    timeline of the last frame: start, duration, queue"""
 import csv
 import os
@@ -11,25 +11,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(w, h, n):
+def run(w, h, n, B=1):
     import time
     import torch
     import sift_amd
     dev = torch.device("cuda", 0)
-    ctx = sift_amd.SiftGPU(max_width=w, max_height=h, max_batch=1, device=0)
-    frame = torch.empty(w * h * 3, dtype=torch.uint8, device=dev)
-    ctx.synth_vnoise5(frame.data_ptr(), w, h, 1234)
+    ctx = sift_amd.SiftGPU(max_width=w, max_height=h, max_batch=B, device=0)
+    frame = torch.empty(B * w * h * 3, dtype=torch.uint8, device=dev)
+    for i in range(B):
+        ctx.synth_vnoise5(frame.data_ptr() + i * w * h * 3, w, h, 1234 + i)
     cap = w * h // 40 + 4096
-    out = torch.empty(cap * 144, dtype=torch.uint8, device=dev)
-    cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+    out = torch.empty(B * cap * 144, dtype=torch.uint8, device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
     ctx.sync()
     ts = []
     for i in range(n):
         t0 = time.perf_counter()
-        ctx.extract_batch_device(frame.data_ptr(), 1, w, h, 3, out.data_ptr(), cap, cnt.data_ptr())
+        ctx.extract_batch_device(frame.data_ptr(), B, w, h, 3, out.data_ptr(), cap, cnt.data_ptr())
         ctx.sync()
         ts.append(time.perf_counter() - t0)
-    print("features %d, median %.3f ms, best %.3f ms" % (int(cnt.item()), 1e3 * sorted(ts)[len(ts) // 2], 1e3 * min(ts)))
+    print("features %d, median %.3f ms, best %.3f ms%s" % (int(cnt[0].item()), 1e3 * sorted(ts)[len(ts) // 2], 1e3 * min(ts),
+                                                          "" if B == 1 else " per call of %d frames" % B))
     ctx.close()
 
 
@@ -55,4 +57,5 @@ if __name__ == "__main__":
         read(sys.argv[2])
     else:
         a = sys.argv[2:]
-        run(int(a[0]) if len(a) > 1 else 1920, int(a[1]) if len(a) > 1 else 1080, int(a[2]) if len(a) > 2 else 30)
+        run(int(a[0]) if len(a) > 1 else 1920, int(a[1]) if len(a) > 1 else 1080, int(a[2]) if len(a) > 2 else 30,
+            int(a[3]) if len(a) > 3 else 1)

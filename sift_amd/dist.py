@@ -47,14 +47,14 @@ def allgather_features_v(packed, counts, cap, group=None):
     B = counts.numel()
     all_counts = torch.empty(world * B, dtype=counts.dtype, device=counts.device)
     dist.all_gather_into_tensor(all_counts, counts.reshape(-1).contiguous(), group=group)
-    per = all_counts.reshape(world, B).clamp(max=cap).to(torch.int64)
-    totals = per.sum(dim=1).cpu().tolist()
+    per = all_counts.reshape(world, B).clamp(max=cap).to(torch.int64).cpu()  # one transfer: the sizes are host-side from here
     rank_first = [0]
-    for t in totals:
+    for t in per.sum(dim=1).tolist():
         rank_first.append(rank_first[-1] + int(t))
     out = torch.empty(rank_first[-1] * 144, dtype=torch.uint8, device=packed.device)
     slots = packed.reshape(B, cap * 144)
-    mine = torch.cat([slots[i, : int(per[rank, i]) * 144] for i in range(B)]) if B else out[:0]
+    mine_counts = per[rank].tolist()
+    mine = torch.cat([slots[i, : mine_counts[i] * 144] for i in range(B)]) if B else out[:0]
     out[rank_first[rank] * 144: rank_first[rank + 1] * 144] = mine
     for r in range(world):
         if rank_first[r + 1] > rank_first[r]:

@@ -52,11 +52,20 @@ def main():
         MAX_W, MAX_H = int(sys.argv[3]), int(sys.argv[4])
     ctx = {}
 
-    def context(ni, sigma):
-        if (ni, sigma) not in ctx:
-            ctx[(ni, sigma)] = sift_amd.SiftGPU(max_width=MAX_W, max_height=MAX_H, max_batch=2,
-                                                max_features=MAX_W * MAX_H // 2, nointerval=bool(ni), sigma=sigma)
-        return ctx[(ni, sigma)]
+    room = {}  # (detector, sigma) -> features per frame the context was made for
+
+    def context(ni, sigma, need=0):
+        """The context of a detector and base sigma; with need: one with room for that many features per frame (an
+        image denser than the default sizing -- fine checkerboards at a small sigma -- reports SG_E_CAPACITY and says
+        how much it needs, and the case runs again, as the host layer does it)."""
+        key = (ni, sigma)
+        if key in ctx and need > room[key]:
+            ctx.pop(key).close()
+        if key not in ctx:
+            room[key] = max(MAX_W * MAX_H // 2, need)
+            ctx[key] = sift_amd.SiftGPU(max_width=MAX_W, max_height=MAX_H, max_batch=2, max_features=room[key],
+                                        nointerval=bool(ni), sigma=sigma)
+        return ctx[key]
 
     bad = 0
     feats_total = 0
@@ -73,7 +82,13 @@ def main():
         c = context(int(ni), sigma)
         try:
             ref, n_kp, ctr, _ = O.sift(img, sigma=sigma, nointerval=ni)
-            got = c.extract(img, cap=MAX_W * MAX_H)
+            try:
+                got = c.extract(img, cap=MAX_W * MAX_H)
+            except sift_amd.SiftGpuError as e:
+                if e.status != sift_amd.api.SG_E_CAPACITY:
+                    raise
+                c = context(int(ni), sigma, need=c.required_features() + 1024)
+                got = c.extract(img, cap=max(MAX_W * MAX_H, room[(int(ni), sigma)]))
             problems = []
             if tuple(c.read_counters()) != tuple(ctr):
                 problems.append("counters %s != %s" % (c.read_counters(), ctr))
@@ -106,7 +121,7 @@ def main():
                 if not np.allclose(got["scale"], ref["scale"], rtol=1e-13, atol=0):
                     problems.append("scale")
             if k % 10 == 0 and not problems:
-                two = c.extract_batch(np.stack([img[::-1].copy(), img]), MAX_W * MAX_H // 2)[1]
+                two = c.extract_batch(np.stack([img[::-1].copy(), img]), room[(int(ni), sigma)])[1]
                 if len(two) != len(ref) or (len(ref) and not np.array_equal(two["desc"], ref["descriptor"].astype(np.uint8))):
                     problems.append("second frame of a batch differs")
             # every fifth case: the matcher on this case's and the previous checked case's features (checkerboards

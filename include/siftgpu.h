@@ -145,6 +145,14 @@ typedef struct sg_wire_feature {
 int sg_extract_batch_begin(sg_ctx *ctx, const uint8_t *const *imgs, int n_img, int width, int height, int channels,
                            size_t stride, int pinned, uint32_t *counts);
 int sg_extract_batch_fetch_wire(sg_ctx *ctx, sg_wire_feature *out, size_t cap_total);
+/* The same download in pieces (what Sift() appends to the caller's vector, sift.cpp:1646-1707, on its way over the bus):
+ * _begin packs the records and enqueues their transfer image after image in pieces of at most piece_records records
+ * (same layout in `out` as above), *n_pieces receives how many; it returns without waiting.  _wait(k) returns once
+ * piece k -- and with it every piece before it -- lies in `out`, so the caller can expand piece k while piece k + 1 is
+ * still on the bus.  A new sg_extract_batch_begin (or any other call that runs the path) forgets the pieces. */
+int sg_extract_batch_fetch_wire_begin(sg_ctx *ctx, sg_wire_feature *out, size_t cap_total, size_t piece_records,
+                                      int *n_pieces);
+int sg_extract_batch_fetch_wire_wait(sg_ctx *ctx, int piece);
 void sg_expand_wire(const sg_wire_feature *in, size_t n, sg_keypoint *out);
 /* Page-locked host memory for the two calls above (hipHostMalloc / hipHostFree). */
 int sg_host_alloc(size_t bytes, void **ptr);

@@ -40,6 +40,7 @@ assert PACKED_DTYPE.itemsize == 144
 EXPORTS = (
     "sg_default_params", "sg_strerror", "sg_last_error", "sg_device_count", "sg_create", "sg_destroy", "sg_sync", "sg_required_features",
     "sg_extract", "sg_extract_begin", "sg_extract_fetch", "sg_extract_batch_begin", "sg_extract_batch_fetch_wire",
+    "sg_extract_batch_fetch_wire_begin", "sg_extract_batch_fetch_wire_wait",
     "sg_expand_wire", "sg_host_alloc", "sg_host_free", "sg_extract_batch_device", "sg_extract_batch", "sg_convert_to_gray", "sg_upsample",
     "sg_downsample", "sg_gaussian_smooth", "sg_create_init_smooth_gray", "sg_gaussian_pyramid", "sg_sub",
     "sg_dog_pyramid", "sg_detect_local_extrema", "sg_calculate_scale", "sg_half_features",
@@ -103,6 +104,8 @@ def load_library():
     L.sg_extract_batch_begin.argtypes = [vp, C.POINTER(u8p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_size_t, C.c_int,
                                          C.POINTER(C.c_uint32)]
     L.sg_extract_batch_fetch_wire.argtypes = [vp, vp, C.c_size_t]
+    L.sg_extract_batch_fetch_wire_begin.argtypes = [vp, vp, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+    L.sg_extract_batch_fetch_wire_wait.argtypes = [vp, C.c_int]
     L.sg_expand_wire.argtypes = [vp, C.c_size_t, vp]
     L.sg_expand_wire.restype = None
     L.sg_host_alloc.argtypes = [C.c_size_t, C.POINTER(vp)]
@@ -248,9 +251,11 @@ class SiftGPU:
         self._check(rc)
         return [out[i, : counts[i]].copy() for i in range(n)]
 
-    def extract_batch_wire(self, imgs, pinned=False):
+    def extract_batch_wire(self, imgs, pinned=False, piece_records=0):
         """Several host images of one size in one batch -> list of KEYPOINT_DTYPE arrays (sg_extract_batch_begin,
-        sg_extract_batch_fetch_wire, sg_expand_wire).  pinned: stage images and records in page-locked memory."""
+        sg_extract_batch_fetch_wire, sg_expand_wire).  pinned: stage images and records in page-locked memory.
+        piece_records > 0: the records come down in pieces of that many (sg_extract_batch_fetch_wire_begin / _wait),
+        every piece expanded as soon as it has landed."""
         imgs = np.ascontiguousarray(imgs, dtype=np.uint8)
         n, h, w, ch = imgs.shape
         ptrs = (C.POINTER(C.c_uint8) * n)()
@@ -270,9 +275,24 @@ class SiftGPU:
                 self.lib.sg_host_free(host_in)
         total = sum(counts)
         wire = np.zeros(max(total, 1), dtype=WIRE_DTYPE)
-        self._check(self.lib.sg_extract_batch_fetch_wire(self.ctx, wire.ctypes.data, total))
         recs = np.zeros(max(total, 1), dtype=KEYPOINT_DTYPE)
-        self.lib.sg_expand_wire(wire.ctypes.data, total, recs.ctypes.data)
+        if piece_records > 0:
+            n_pieces = C.c_int(0)
+            self._check(self.lib.sg_extract_batch_fetch_wire_begin(self.ctx, wire.ctypes.data, total, piece_records,
+                                                                   C.byref(n_pieces)))
+            k = 0
+            for i in range(n):  # pieces follow the images: every image is cut into pieces of its own
+                first = sum(counts[:i])
+                for off in range(0, counts[i], piece_records):
+                    m = min(piece_records, counts[i] - off)
+                    self._check(self.lib.sg_extract_batch_fetch_wire_wait(self.ctx, k))
+                    self.lib.sg_expand_wire(wire.ctypes.data + (first + off) * WIRE_DTYPE.itemsize, m,
+                                            recs.ctypes.data + (first + off) * KEYPOINT_DTYPE.itemsize)
+                    k += 1
+            assert k == n_pieces.value, (k, n_pieces.value)
+        else:
+            self._check(self.lib.sg_extract_batch_fetch_wire(self.ctx, wire.ctypes.data, total))
+            self.lib.sg_expand_wire(wire.ctypes.data, total, recs.ctypes.data)
         out, at = [], 0
         for i in range(n):
             out.append(recs[at: at + counts[i]].copy())

@@ -173,6 +173,8 @@ struct sg_ctx {
     size_t pending_features = 0; // feature count of the last sg_extract_begin, not fetched yet
     bool have_pending = false;
     std::vector<uint32_t> pending_counts; // per image, of the last sg_extract_batch_begin (empty: none pending)
+    std::vector<hipEvent_t> chunk_ev;     // sg_extract_batch_fetch_wire_begin: one per piece of the download
+    int chunks_pending = 0;               // pieces of the download in flight (0: none)
     size_t out_bytes = 0;
     unsigned int *d_outcounts = nullptr;
 
@@ -405,6 +407,7 @@ static void invalidate_pending(sg_ctx *c)
 {
     c->have_pending = false;
     c->pending_counts.clear();
+    c->chunks_pending = 0;
 }
 
 constexpr double kDetectThreshold = 0.5 * 0.03 / 3; // 0.5 * DXTHRESHOLD / intervals (sift.cpp:924)
@@ -894,6 +897,9 @@ int sg_destroy(sg_ctx *c)
             (void)hipEventDestroy(c->ev.start[i]);
             (void)hipEventDestroy(c->ev.stop[i]);
         }
+    for (hipEvent_t e : c->chunk_ev)
+        if (e)
+            (void)hipEventDestroy(e);
     if (c->side) {
         (void)hipStreamSynchronize(c->side);
         (void)hipStreamDestroy(c->side);
@@ -1294,6 +1300,64 @@ int sg_extract_batch_fetch_wire(sg_ctx *c, sg_wire_feature *out, size_t cap_tota
     return SG_OK;
 }
 
+
+// The same download in pieces the caller can wait for one by one (and expand while the next is on the bus).
+int sg_extract_batch_fetch_wire_begin(sg_ctx *c, sg_wire_feature *out, size_t cap_total, size_t piece_records, int *n_pieces)
+{
+    if (!c || (cap_total && !out) || !n_pieces || piece_records == 0)
+        return SG_E_INVALID;
+    *n_pieces = 0;
+    c->chunks_pending = 0;
+    if (c->pending_counts.empty())
+        return fail(c, SG_E_INVALID, "sg_extract_batch_fetch_wire_begin without a successful sg_extract_batch_begin before it");
+    (void)hipSetDevice(c->prm.device);
+    const int n_img = (int)c->pending_counts.size();
+    size_t total = 0, widest = 0;
+    for (uint32_t v : c->pending_counts) {
+        total += v;
+        widest = std::max<size_t>(widest, v);
+    }
+    if (total > cap_total)
+        return fail(c, SG_E_CAPACITY, "output array too small");
+    if (total == 0)
+        return SG_OK;
+    int rc = ensure_out(c, sizeof(WireRec) * widest * n_img);
+    if (rc != SG_OK)
+        return rc;
+    pack_phase(c, c->d_out, widest, (unsigned int)widest, nullptr, 3, 1, n_img);
+    HIPCHK(c, hipGetLastError());
+    // Pieces follow the output order: image after image, every image cut into pieces of at most piece_records.
+    size_t at = 0;
+    int k = 0;
+    for (int i = 0; i < n_img; i++) {
+        const size_t cnt = c->pending_counts[i];
+        for (size_t off = 0; off < cnt; off += piece_records) {
+            const size_t m = std::min(piece_records, cnt - off);
+            HIPCHK(c, hipMemcpyAsync(out + at + off, (const WireRec *)c->d_out + widest * i + off, m * sizeof(WireRec),
+                                     hipMemcpyDeviceToHost, c->stream));
+            if ((size_t)k >= c->chunk_ev.size()) {
+                hipEvent_t e = nullptr;
+                HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                c->chunk_ev.push_back(e);
+            }
+            HIPCHK(c, hipEventRecord(c->chunk_ev[(size_t)k], c->stream));
+            k++;
+        }
+        at += cnt;
+    }
+    c->chunks_pending = k;
+    *n_pieces = k;
+    return SG_OK;
+}
+
+int sg_extract_batch_fetch_wire_wait(sg_ctx *c, int piece)
+{
+    if (!c || piece < 0 || piece >= c->chunks_pending)
+        return SG_E_INVALID;
+    (void)hipSetDevice(c->prm.device);
+    HIPCHK(c, hipEventSynchronize(c->chunk_ev[(size_t)piece]));
+    return SG_OK;
+}
 
 int sg_host_alloc(size_t bytes, void **ptr)
 {

@@ -39,6 +39,7 @@ struct sg_ctx {
     unsigned long long calls = 0; // plain field, written by every call: races show under ThreadSanitizer
     std::vector<std::vector<sg_wire_feature>> pending;
     std::vector<sg_counters> counters;
+    int pieces = 0;
 };
 
 extern "C" {
@@ -208,6 +209,24 @@ int sg_extract_batch_fetch_wire(sg_ctx *c, sg_wire_feature *out, size_t cap_tota
     }
     return SG_OK;
 }
+
+int sg_extract_batch_fetch_wire_begin(sg_ctx *c, sg_wire_feature *out, size_t cap_total, size_t piece_records, int *n_pieces)
+{
+    if (!c || !n_pieces || piece_records == 0)
+        return SG_E_INVALID;
+    *n_pieces = 0;
+    const int rc = sg_extract_batch_fetch_wire(c, out, cap_total); // everything "lands" at once here
+    if (rc != SG_OK)
+        return rc;
+    int k = 0;
+    for (const auto &v : c->pending)
+        k += (int)((v.size() + piece_records - 1) / piece_records);
+    c->pieces = k;
+    *n_pieces = k;
+    return SG_OK;
+}
+
+int sg_extract_batch_fetch_wire_wait(sg_ctx *c, int piece) { return c && piece >= 0 && piece < c->pieces ? SG_OK : SG_E_INVALID; }
 
 // ---- what the tests read back ----
 int fake_sg_creates(void) { return g_creates.load(); }

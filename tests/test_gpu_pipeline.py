@@ -1,4 +1,6 @@
 """Parity of the whole path through the C ABI against the CPU oracle on the same seeded inputs."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -232,14 +234,22 @@ def test_batch_wire_records_equal_single_image_records(oracle, pinned):
             return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
         for a, b in zip(got, singles):
             assert same(a, b)
+        # the same records when they come down in pieces (a piece per 37 records: images end inside pieces' ranges)
+        for a, b in zip(g.extract_batch_wire(imgs, pinned=pinned, piece_records=37), singles):
+            assert same(a, b)
+        n_pieces = C.c_int(0)
+        assert g.lib.sg_extract_batch_fetch_wire_wait(g.ctx, 10 ** 6) == sift_amd.api.SG_E_INVALID
         # fewer images than the context's batch, and a fetch into too small an array
         got = g.extract_batch_wire(imgs[:2], pinned=pinned)
         assert same(got[1], singles[1])
         wire = np.zeros(4, dtype=sift_amd.WIRE_DTYPE)
         assert g.lib.sg_extract_batch_fetch_wire(g.ctx, wire.ctypes.data, 4) == sift_amd.api.SG_E_CAPACITY
+        assert g.lib.sg_extract_batch_fetch_wire_begin(g.ctx, wire.ctypes.data, 4, 16, C.byref(n_pieces)) == sift_amd.api.SG_E_CAPACITY
         # a single-image call in between drops the pending batch
         g.extract(imgs[0])
         assert g.lib.sg_extract_batch_fetch_wire(g.ctx, wire.ctypes.data, 4) == sift_amd.api.SG_E_INVALID
+        assert g.lib.sg_extract_batch_fetch_wire_begin(g.ctx, wire.ctypes.data, 4, 16, C.byref(n_pieces)) == sift_amd.api.SG_E_INVALID
+        assert g.lib.sg_extract_batch_fetch_wire_wait(g.ctx, 0) == sift_amd.api.SG_E_INVALID
 
 
 def test_batch_device_output_at_unaligned_address(oracle, gpu64):

@@ -152,6 +152,8 @@ int launch_detect(const OctaveTab &tab, int B, unsigned long long *words, size_t
 void launch_scan(unsigned int *chunk_sums, size_t chunks_img_stride, int n_chunks, unsigned int *totals,
                  unsigned int cap, unsigned int *overflow, int B, hipStream_t s);
 // expand set bits of words (n_words per image) into out[b][pos] = word*64 + bit, ordered
+// host-side copy into a page-locked staging buffer (streaming stores where the CPU has them; sg_wire.cpp)
+void copy_to_staging(void *dst, const void *src, size_t len);
 // per-chunk popcounts of a bitmap (n_chunks values per image), for producers that leave the counting to this launch
 void launch_chunk_popc(const unsigned long long *words, size_t words_img_stride, unsigned int n_words,
                        const unsigned int *dyn_items, unsigned int items_per_word, unsigned int *chunk_sums,

@@ -1182,7 +1182,7 @@ int sg_extract_begin(sg_ctx *c, const uint8_t *px, int width, int height, int ch
             HIPCHK(c, hipMemcpyAsync(c->d_in, px, nbytes, hipMemcpyHostToDevice, c->stream));
         for (size_t at = 0; pinned && at < nbytes; at += kUploadPiece) { // a piece is on the bus while the next is copied
             const size_t len = std::min(kUploadPiece, nbytes - at);
-            memcpy(c->h_in + at, px + at, len);
+            copy_to_staging(c->h_in + at, px + at, len);
             HIPCHK(c, hipMemcpyAsync(c->d_in + at, c->h_in + at, len, hipMemcpyHostToDevice, c->stream));
         }
     }
@@ -1248,7 +1248,7 @@ int sg_extract_batch_begin(sg_ctx *c, const uint8_t *const *imgs, int n_img, int
         // through the page-locked buffer a piece at a time: the transfer of one piece runs while the next is copied
         for (size_t at = 0; at < nbytes; at += kUploadPiece) {
             const size_t len = std::min(kUploadPiece, nbytes - at);
-            memcpy(c->h_in + img_bytes * i + at, imgs[i] + at, len);
+            copy_to_staging(c->h_in + img_bytes * i + at, imgs[i] + at, len);
             HIPCHK(c, hipMemcpyAsync(c->d_in + img_bytes * i + at, c->h_in + img_bytes * i + at, len,
                                      hipMemcpyHostToDevice, c->stream));
         }

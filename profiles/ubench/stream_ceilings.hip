@@ -47,6 +47,35 @@ __global__ __launch_bounds__(64 * NW) void strip_k(const double *__restrict__ sr
     }
 }
 
+// The same walk with other read : write mixes, as the pyramid's launches have them: RDIV = 0 writes only, RDIV = n reads
+// one input row per n output rows (the base blur reads a quarter-size gray plane: 1 byte read per 4 written), NOUT = 2
+// writes two planes per plane read (levels 1 and 2 of an octave from one launch).  Four waves per block, 128 columns
+// per wave, segments of `seg` rows.  The reported rate counts the bytes actually moved.
+template <int RDIV, int NOUT>
+__global__ __launch_bounds__(256) void strip_mix_k(const double *__restrict__ src, double *__restrict__ dst, double *__restrict__ dst2, int rows, int cols, int pitch, size_t img, int seg, int nseg, int nsx)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int id = blockIdx.x;
+    const int bx = id % nsx; id /= nsx;
+    const int sidx = id % nseg; const int z = id / nseg;
+    const int x = (bx * 4 + wave) * 128 + lane * 2;
+    const int ys = sidx * seg;
+    if (ys >= rows || x >= cols) return;
+    const int ye = min(ys + seg, rows);
+    const double *s = src + z * img + x;
+    double *d = dst + z * img + x, *d2 = dst2 + z * img + x;
+    double2 v = {1.0, 2.0};
+    for (int y = ys; y < ye; y++) {
+        if (RDIV > 0 && (y - ys) % RDIV == 0) {
+            const double2 r = *(const double2 *)(s + (size_t)(RDIV > 1 ? ys + (y - ys) / RDIV : y) * pitch);
+            v.x += r.x; v.y += r.y;
+        }
+        v.x = v.x * 1.0000001 + 1.0;
+        *(double2 *)(d + (size_t)y * pitch) = v;
+        if (NOUT == 2) { v.y += 1.0; *(double2 *)(d2 + (size_t)y * pitch) = v; }
+    }
+}
+
 __global__ __launch_bounds__(256) void linear_k(const double2 *__restrict__ src, double2 *__restrict__ dst, size_t n)
 {
     for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { double2 v = src[i]; v.x += 1.0; dst[i] = v; }
@@ -80,6 +109,27 @@ int main(int argc, char **argv)
     timeit("linear copy x32 blocks", 2.0 * n * 8, [&] { linear_k<<<256 * 32, 256>>>((const double2 *)a, (double2 *)b, n / 2); });
     timeit("read only", 1.0 * n * 8, [&] { read_k<<<256 * 16, 256>>>((const double2 *)a, b, n / 2); });
     timeit("write only", 1.0 * n * 8, [&] { write_k<<<256 * 16, 256>>>((double2 *)b, n / 2); });
+    {
+        double *c2;
+        CK(hipMalloc(&c2, n * 8));
+        CK(hipMemset(c2, 0, n * 8));
+        const int mix_segs[3] = {2160, 540, 136};
+        for (int seg : mix_segs) {
+            const int nseg = (rows + seg - 1) / seg, nsx = (cols / 128 + 3) / 4, tot = nsx * nseg * B;
+            char nm[96];
+            snprintf(nm, 96, "strip walk, write only, seg %d", seg);
+            timeit(nm, 1.0 * n * 8, [&] { strip_mix_k<0, 1><<<tot, 256>>>(a, b, c2, rows, cols, cols, img, seg, nseg, nsx); });
+            snprintf(nm, 96, "strip walk, 1 read : 4 written, seg %d", seg);
+            timeit(nm, 1.25 * n * 8, [&] { strip_mix_k<4, 1><<<tot, 256>>>(a, b, c2, rows, cols, cols, img, seg, nseg, nsx); });
+            snprintf(nm, 96, "strip walk, 1 read : 1 written, seg %d", seg);
+            timeit(nm, 2.0 * n * 8, [&] { strip_mix_k<1, 1><<<tot, 256>>>(a, b, c2, rows, cols, cols, img, seg, nseg, nsx); });
+            snprintf(nm, 96, "strip walk, 1 read : 2 written, seg %d", seg);
+            timeit(nm, 3.0 * n * 8, [&] { strip_mix_k<1, 2><<<tot, 256>>>(a, b, c2, rows, cols, cols, img, seg, nseg, nsx); });
+        }
+        CK(hipFree(c2));
+    }
+    if (argc > 2 && atoi(argv[2]) == 0)
+        return 0; // the mixes only
     int segs[16] = {540, 270, 136, 68}, nsegs = 4;
     if (argc > 2) { nsegs = 0; for (int i = 2; i < argc && nsegs < 16; i++) segs[nsegs++] = atoi(argv[i]); }
     for (int si = 0; si < nsegs; si++) {

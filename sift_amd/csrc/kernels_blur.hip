@@ -475,6 +475,9 @@ constexpr int win_waves_per_simd(int R) { return R <= 6 ? SG_WIN_WPE6 : (R <= 8 
 #endif
 constexpr int win_rows_per_iter(int R) { return R > 10 ? SG_WIN_KR13 : 2; }
 
+#ifndef SG_UPS_DI
+#define SG_UPS_DI 3
+#endif
 // Gray rows of the upsampling form staged by direct-to-LDS loads (GDMA): geometry of a wave's ring.
 template <typename T, int R, int V>
 struct WinGray {
@@ -484,10 +487,14 @@ struct WinGray {
     static constexpr int NP = (GCOLS + 1) / 2;                             // 16-byte pieces (two doubles) per gray row
     static constexpr int NI = (NP + 63) / 64;                              // load instructions per gray row
     static constexpr int ROWB = NP * 16, ROWE = NP * 2;
-    static constexpr int DI = 3;                                           // iterations in the ring
-    static constexpr int SLOTB = KR * 2 * ROWB;                            // two gray rows per output row
+    static constexpr int DI = SG_UPS_DI;                                   // iterations in the ring
+    // The KR consecutive output rows of an iteration (after reflection at the border and the repeat of the last rows:
+    // still rows next to each other, or the same row) are formed from KR / 2 + 1 consecutive gray rows: an odd row
+    // 2i + 1 needs gray rows i and i + 1, the even rows beside it need i or i + 1.
+    static constexpr int GROWS = KR / 2 + 1;                               // gray rows staged per iteration
+    static constexpr int SLOTB = GROWS * ROWB;
     static constexpr int WAVE_BYTES = DI * SLOTB;
-    static constexpr int PER = KR * 2 * NI;                                // load instructions per iteration
+    static constexpr int PER = GROWS * NI;                                 // load instructions per iteration
     static_assert((DI - 1) * PER < 64, "outstanding loads fit the counter");
 };
 
@@ -554,20 +561,24 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
 #pragma unroll
     for (int q = 0; q < GR::NI; q++)
         gvoff[q] = (unsigned int)min(max(jb + 2 * (lane + 64 * q), 0), spitch - 2) * 8u;
+    auto gray_first = [&](int t) { // first of the gray rows iteration t's output rows are formed from (wave-uniform)
+        int g = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < KR; k++)
+            g = min(g, min(reflect101_once(ys - R + KR * t + k, rows), rows - 3) >> 1);
+        return g;
+    };
     auto stage_gray = [&](int t) { // iteration t's gray rows into slot t mod DI
+        const int g_first = gray_first(t);
 #pragma unroll
-        for (int k = 0; k < KR; k++) {
-            const int yy = reflect101_once(ys - R + KR * t + k, rows);
-            const int gi = min(yy, rows - 3) >> 1;
+        for (int h = 0; h < GR::GROWS; h++) {
+            const int gr = min(g_first + h, (rows >> 1) - 1);
+            const unsigned long long base = (unsigned long long)(uintptr_t)(gsrc + (size_t)gr * spitch);
+            const unsigned int to = lds_gring + (unsigned int)((t % GR::DI) * GR::SLOTB + h * GR::ROWB);
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const unsigned long long base = (unsigned long long)(uintptr_t)(gsrc + (size_t)(gi + h) * spitch);
-                const unsigned int to = lds_gring + (unsigned int)((t % GR::DI) * GR::SLOTB + (k * 2 + h) * GR::ROWB);
-#pragma unroll
-                for (int q = 0; q < GR::NI; q++)
-                    if (q + 1 < GR::NI || lane < GR::NP - 64 * (GR::NI - 1))
-                        load16_to_lds(to + 1024u * q, base, gvoff[q]);
-            }
+            for (int q = 0; q < GR::NI; q++)
+                if (q + 1 < GR::NI || lane < GR::NP - 64 * (GR::NI - 1))
+                    load16_to_lds(to + 1024u * q, base, gvoff[q]);
         }
     };
     int uj[V], uo[V]; // j and column parity of the lane's elements, and of its halo column
@@ -596,9 +607,9 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                 const int yc = min(yy, rows - 3);
                 const bool oddr = (yc & 1) != 0; // wave-uniform
                 const double *g0, *g1;
-                if (GDMA) { // element 0 of a staged row is gray column jb
-                    g0 = gring + ((t % GR::DI) * (GR::SLOTB / 8) + (k * 2) * GR::ROWE) - jb;
-                    g1 = g0 + GR::ROWE;
+                if (GDMA) { // element 0 of a staged row is gray column jb; the slot starts at gray row gray_first(t)
+                    g0 = gring + ((t % GR::DI) * (GR::SLOTB / 8) + ((yc >> 1) - gray_first(t)) * GR::ROWE) - jb;
+                    g1 = g0 + GR::ROWE; // (read for odd rows only, which sit on the slot's first row or share it: see WinGray)
                 } else {
                     g0 = gsrc + (size_t)(yc >> 1) * spitch;
                     g1 = g0 + spitch;
@@ -715,10 +726,17 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
 #pragma unroll
                     for (int vo = 0; vo < V; vo++) {
                         const int tt = e - vo;
+#ifdef SG_X_WIN_NOROW // timing experiment: the row filter keeps two terms per output
+                        if (tt == 0)
+                            po[vo] = taps.k[0] * pv[j];
+                        else if (tt == 2 * R)
+                            po[vo] = po[vo] + pv[j];
+#else
                         if (tt == 0)
                             po[vo] = taps.k[0] * pv[j];
                         else if (tt > 0 && tt <= 2 * R)
                             po[vo] = blur_madd<F>(po[vo], taps.k[tt], pv[j]);
+#endif
                     }
                 }
             }
@@ -738,8 +756,13 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
 #pragma unroll
                 for (int e = 0; e < V; e++)
                     pa[e] = taps.k[R] * pc[e];
+#ifdef SG_X_WIN_NOCOL // timing experiment: the column filter keeps its outermost pair
+#pragma unroll
+                for (int tt = R; tt <= R; tt++) {
+#else
 #pragma unroll
                 for (int tt = 1; tt <= R; tt++) {
+#endif
                     const T *pu = reinterpret_cast<const T *>(&win[R + k + tt]);
                     const T *pd = reinterpret_cast<const T *>(&win[R + k - tt]);
 #pragma unroll
@@ -747,7 +770,11 @@ void blur_win_k(const T *__restrict__ src, T *__restrict__ dst, int rows, int co
                         pa[e] = blur_madd<F>(pa[e], taps.k[R + tt], pu[e] + pd[e]);
                 }
                 const int y = ys + n0 + k;
+#ifdef SG_X_WIN_NOSTORE // timing experiment: (almost) nothing is written
+                if (y < ye && pa[0] == (T)123.456) {
+#else
                 if (y < ye) {
+#endif
                     T *dr = d + (size_t)y * dpitch;
                     if (strip_full) {
                         *reinterpret_cast<vec_t *>(dr + xb) = acc;

@@ -557,6 +557,14 @@ def main():
     import sift_amd
     from sift_amd import dist as sdist
 
+    # The host-API programs (Sift() through the C++ layer, compiled programs of their own) are measured before this
+    # process opens the GPU: a second process with queues on the device -- even an idle one -- makes the hardware
+    # scheduler switch between the two, which a call that is a chain of fifty dependent launches feels (one Sift()
+    # call 2.2 -> 2.5 ms, sixteen threads with a context each 870 -> 600 calls/s when measured from inside).
+    host_api_early = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        host_api_early = host_api_throughput(args.width, args.height, 0, args.cpu_threads)
+        host_api_early["multi_gpu_driver"] = host_multi_gpu_driver(args.width, args.height, 1, 128)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback)")
     # One GPU per rank.  For a rehearsal of the N > 1 control flow on a box with fewer GPUs than ranks, ranks wrap
@@ -879,8 +887,8 @@ def main():
     if not args.no_extras:
         verify, latency = batch_check_and_latency(sift_amd, torch, dev, dev_index, prec, W, H, cap, frames, frame_bytes,
                                                   last_first, B, outs[last_buf[0]], feat_counts)
-        host_api = host_api_throughput(W, H, dev_index, args.cpu_threads)
-        if world == 1 or args.host_multi:
+        host_api = host_api_early or host_api_throughput(W, H, dev_index, args.cpu_threads)
+        if host_api_early is None and (world == 1 or args.host_multi):
             host_api["multi_gpu_driver"] = host_multi_gpu_driver(W, H, world, 128 * world)
     overlap = f64_fma = None
     if not args.no_extras and args.precision == "f64" and (W, H) == (1920, 1080):

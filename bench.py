@@ -396,10 +396,13 @@ def preflight_child():
     With several ranks the C ABI's exchange (sg_comm_create, sg_allgather_features: the library's own RCCL binding)
     meets real peers for the first time, and a collective that never returns cannot be left from inside the process
     that entered it.  So before the measured processes allocate anything, every rank starts this program: the ranks
-    meet over gloo on a port of their own, build an RCCL communicator through the C ABI, all-gather two sets of
-    patterned records with ragged counts (a frame without features among them) and compare every gathered byte and
-    count with what the pattern says.  Exit status 0: the exchange works on this node; anything else (or no exit
-    within the parent's time limit) sends the measured run through torch.distributed's all-gather instead."""
+    meet over gloo on a port of their own, build an RCCL communicator through the C ABI and run the all-gather-v in
+    both of its forms (one broadcast per slot; point-to-point sends and receives): per form two sets of patterned
+    records with ragged counts (a frame without features among them), every gathered byte and count compared with
+    what the pattern says, then three timed rounds.  One line of JSON per form on stdout as soon as the form is
+    through.  The parents take the point-to-point form where it worked on every rank and was not slower, else the
+    broadcasts; if neither worked (or the child did not return within the parent's time limit) the measured run
+    exchanges through torch.distributed's all-gather instead."""
     import datetime
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -433,41 +436,68 @@ def preflight_child():
     comm = ctx.comm_create(ids[0], rank, world)
     mark("communicator built")
     n_img, cap, words = 4, 65536, 144 // 8  # 38 MB of padded records per rank
-    ok = True
-    for trial in range(2):
-        def counts_of(r):
-            return [((r * 7919 + i * 104729 + trial * 31337 + 12345) % cap) if (r + i + trial) % 5 else 0
-                    for i in range(n_img)]
 
-        def tag(r):
-            return (r << 48) | (trial << 40)
+    def run_form(form):
+        """Two checked rounds and three timed ones of the all-gather-v in one of its forms; (ok, milliseconds)."""
+        os.environ["SIFTGPU_ALLGATHERV"] = form  # read by the library at every call
+        ok, best = True, None
+        for trial in range(5):
+            def counts_of(r):
+                return [((r * 7919 + i * 104729 + trial * 31337 + 12345) % cap) if (r + i + trial) % 5 else 0
+                        for i in range(n_img)]
 
-        mine = torch.arange(n_img * cap * words, dtype=torch.int64, device=dev) ^ tag(rank)
-        counts = torch.tensor(counts_of(rank), dtype=torch.int32, device=dev)
-        cap_all = world * n_img * cap
-        g = torch.full((cap_all * words,), -1, dtype=torch.int64, device=dev)
-        gc = torch.full((world * n_img,), -1, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()
-        mark("entering sg_allgather_features, round %d" % trial)
-        first = ctx.allgather_features(comm, mine.data_ptr(), counts.data_ptr(), n_img, cap, g.data_ptr(), cap_all,
-                                       gc.data_ptr(), world)
-        ctx.sync()
-        mark("gathered, round %d" % trial)
-        ok = ok and gc.cpu().tolist() == [c for r in range(world) for c in counts_of(r)]
-        at = 0
-        for r in range(world):
-            ok = ok and first[r] == at
-            for i, c in enumerate(counts_of(r)):
-                want = torch.arange(i * cap * words, (i * cap + c) * words, dtype=torch.int64, device=dev) ^ tag(r)
-                ok = ok and torch.equal(g[at * words: (at + c) * words], want)
-                at += c
-        ok = ok and first[world] == at and bool((g[at * words:] == -1).all().item())
+            def tag(r):
+                return (r << 48) | (trial << 40)
+
+            mine = torch.arange(n_img * cap * words, dtype=torch.int64, device=dev) ^ tag(rank)
+            counts = torch.tensor(counts_of(rank), dtype=torch.int32, device=dev)
+            cap_all = world * n_img * cap
+            g = torch.full((cap_all * words,), -1, dtype=torch.int64, device=dev)
+            gc = torch.full((world * n_img,), -1, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            mark("entering sg_allgather_features (%s), round %d" % (form, trial))
+            t0 = time.perf_counter()
+            first = ctx.allgather_features(comm, mine.data_ptr(), counts.data_ptr(), n_img, cap, g.data_ptr(), cap_all,
+                                           gc.data_ptr(), world)
+            ctx.sync()
+            ms = 1e3 * (time.perf_counter() - t0)
+            mark("gathered (%s), round %d" % (form, trial))
+            if trial >= 2:  # the first rounds carry set-up costs of the communicator's channels
+                best = ms if best is None else min(best, ms)
+                continue
+            ok = ok and gc.cpu().tolist() == [c for r in range(world) for c in counts_of(r)]
+            at = 0
+            for r in range(world):
+                ok = ok and first[r] == at
+                for i, c in enumerate(counts_of(r)):
+                    want = torch.arange(i * cap * words, (i * cap + c) * words, dtype=torch.int64, device=dev) ^ tag(r)
+                    ok = ok and torch.equal(g[at * words: (at + c) * words], want)
+                    at += c
+            ok = ok and first[world] == at and bool((g[at * words:] == -1).all().item())
+        return ok, best
+
+    # One form after the other, the result of each on a line of its own as soon as it is known: should the second form
+    # never return, the parent (which ends this process at its time limit) still has the first one's line.  A watchdog
+    # of this process's own ends a form that hangs after 45 s, so that a hang costs less than the parent's whole limit.
+    import threading
+    results = {}
+    for form in ("bcast", "p2p"):
+        dog = threading.Timer(45.0, lambda: os._exit(7))
+        dog.daemon = True
+        dog.start()
+        ok, ms = run_form(form)
+        dog.cancel()
+        results[form] = ok
+        sys.stdout.write(json.dumps({"form": form, "ok": bool(ok), "ms": ms}) + "\n")
+        sys.stdout.flush()
+        mark("form %s: %s" % (form, "all gathered bytes and counts as expected" if ok else "gathered bytes or counts differ"))
     ctx.comm_destroy(comm)
     ctx.close()
     if world > 1:
         dist.destroy_process_group()
-    mark("all gathered bytes and counts as expected" if ok else "gathered bytes or counts differ from the pattern")
-    sys.exit(0 if ok else 3)
+    sys.exit(0 if results.get("bcast") else 3)
 
 
 def preflight_abi_exchange(rank, world, dist, torch, dev):
@@ -487,8 +517,9 @@ def preflight_abi_exchange(rank, world, dist, torch, dev):
     limit = float(os.environ.get("SIFT_BENCH_PREFLIGHT_TIMEOUT", "150"))
     t0 = time.perf_counter()
     why = ""
-    with tempfile.TemporaryFile(mode="w+") as err:
-        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preflight-child"], stdout=subprocess.DEVNULL,
+    forms = {}  # form -> (ok, ms) as this rank's child reported it
+    with tempfile.TemporaryFile(mode="w+") as err, tempfile.TemporaryFile(mode="w+") as out:
+        p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--preflight-child"], stdout=out,
                              stderr=err, env=dict({k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")},
                                                   SIFT_BENCH_PREFLIGHT_PORT=str(port[0])))
         try:
@@ -497,6 +528,13 @@ def preflight_abi_exchange(rank, world, dist, torch, dev):
             p.kill()
             p.wait()
             rc = None
+        out.seek(0)
+        for ln in out.read().splitlines():  # one line per form the child got through, whatever happened after it
+            try:
+                r = json.loads(ln)
+                forms[r["form"]] = (bool(r["ok"]), float(r["ms"]) if r["ms"] is not None else 1e9)
+            except (ValueError, KeyError, TypeError):
+                pass
         if rc != 0:
             err.seek(0)
             lines = err.read().strip().splitlines()
@@ -504,11 +542,22 @@ def preflight_abi_exchange(rank, world, dist, torch, dev):
             errs = [ln for ln in lines if not ln.startswith(("preflight rank", "frame #", " ", "\t"))]
             why = (("no exit within %.0f s" % limit) if rc is None else "exit status %d" % rc) + \
                 ("; got as far as: " + marks[-1][-120:] if marks else "") + ("; " + errs[-1][-200:] if errs else "")
-    t = torch.tensor([1 if rc == 0 else 0], dtype=torch.int32, device=dev if on_dev else "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MIN)
-    return {"ok": bool(t.item()), "this_rank_ok": rc == 0, "this_rank": why or "ok", "seconds": time.perf_counter() - t0,
-            "what": "trial all-gather-v through the C ABI's RCCL binding in child processes (two rounds of patterned "
-                    "records, ragged counts, every byte compared) before the measured processes set up theirs"}
+    where = dev if on_dev else "cpu"
+    oks = torch.tensor([1 if forms.get(f, (False, 0))[0] else 0 for f in ("bcast", "p2p")], dtype=torch.int32, device=where)
+    dist.all_reduce(oks, op=dist.ReduceOp.MIN)  # a form counts when it worked on every rank
+    ms = torch.tensor([forms.get(f, (False, 1e9))[1] for f in ("bcast", "p2p")], dtype=torch.float64, device=where)
+    dist.all_reduce(ms, op=dist.ReduceOp.MAX)
+    bcast_ok, p2p_ok = bool(oks[0].item()), bool(oks[1].item())
+    bcast_ms, p2p_ms = float(ms[0].item()), float(ms[1].item())
+    # the point-to-point form where it worked everywhere and was not slower; else the broadcasts; else torch.distributed
+    form = "p2p" if p2p_ok and (not bcast_ok or p2p_ms <= bcast_ms) else ("bcast" if bcast_ok else None)
+    return {"ok": form is not None, "form": form, "bcast": {"ok": bcast_ok, "ms": bcast_ms if bcast_ok else None},
+            "p2p": {"ok": p2p_ok, "ms": p2p_ms if p2p_ok else None},
+            "this_rank_ok": rc == 0, "this_rank": why or "ok", "seconds": time.perf_counter() - t0,
+            "what": "trial all-gather-v through the C ABI's RCCL binding in child processes, in both of its forms (one "
+                    "broadcast per slot; point-to-point sends and receives): per form two rounds of patterned records "
+                    "with ragged counts, every byte compared, and three timed rounds of 38 MB per rank -- before the "
+                    "measured processes set up theirs; ms = slowest rank's best round"}
 
 
 def main():
@@ -588,6 +637,8 @@ def main():
     if world > 1 and pf_mode != "0" and (use_abi or pf_mode == "force"):
         preflight = preflight_abi_exchange(rank, world, dist, torch, dev)
         use_abi = use_abi and preflight["ok"]
+        if preflight["form"]:
+            os.environ["SIFTGPU_ALLGATHERV"] = preflight["form"]  # the form the library's exchange takes from here on
 
     W, H, B, K, WU = args.width, args.height, args.batch, args.steps, args.warmup
     if args.pool <= 0:
@@ -699,7 +750,9 @@ def main():
                     ok, why = False, repr(e)
                 ok = all_ok(ok)
             if ok:
-                exchange = "sg_allgather_features (RCCL all-gather-v)"
+                exchange = "sg_allgather_features (RCCL all-gather-v, %s)" % (
+                    "point-to-point sends and receives" if os.environ.get("SIFTGPU_ALLGATHERV") == "p2p"
+                    else "one broadcast per slot")
             else:
                 if xctx is not None:
                     xctx.close()

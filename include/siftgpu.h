@@ -308,8 +308,11 @@ int sg_match_packed_device_noalloc(sg_ctx *ctx, const sg_packed_feature *d_f1, u
  * rank's first feature in d_all (rank_first[n_ranks] = total).  SG_E_CAPACITY when the total exceeds cap_all.
  * `comm` is an RCCL communicator (ncclComm_t, passed as void* so that this header needs no rccl.h) created by the
  * caller or by sg_comm_create; NULL means a single rank (no RCCL call is made).  The counts are all-gathered and read
- * by the host (stream synchronisations); the features then move as one grouped set of ncclBroadcast calls,
- * asynchronous on the context's stream (sg_sync waits).  Call it on a context whose stream is not the one a next
+ * by the host (stream synchronisations); the features then move as one grouped set of ncclBroadcast calls (one per
+ * rank's slot) or -- SIFTGPU_ALLGATHERV=p2p in the environment, read at every call, the same on every rank -- point to
+ * point: every rank sends its slot to every peer and receives every peer's, one group of ncclSend / ncclRecv; over a
+ * fully connected xGMI node a slot then crosses each link once.  Either way asynchronous on the context's stream
+ * (sg_sync waits).  Call it on a context whose stream is not the one a next
  * batch is being extracted on if the exchange is to overlap that extraction.
  * Errors are decided by all ranks together where they can be: the ranks first exchange (cap_all, n_img,
  * cap_per_image); differing n_img or cap_per_image give SG_E_INVALID on every rank, and the capacity test uses the

@@ -12,6 +12,7 @@
 // no link-time dependency on it, and a single-GPU caller never touches it.
 #include <dlfcn.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -75,6 +76,8 @@ struct Rccl {
     int (*CommUserRank)(comm_t, int *) = nullptr;
     int (*AllGather)(const void *, void *, size_t, int, comm_t, hipStream_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
+    int (*Send)(const void *, size_t, int, int, comm_t, hipStream_t) = nullptr; // optional: the point-to-point form
+    int (*Recv)(void *, size_t, int, int, comm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
@@ -129,6 +132,10 @@ const Rccl &rccl()
         v.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
         if (!ok)
             v.lib = nullptr;
+        if (v.lib) { // not required: without them the exchange keeps to its broadcast form
+            v.Send = (int (*)(const void *, size_t, int, int, comm_t, hipStream_t))dlsym(v.lib, "ncclSend");
+            v.Recv = (int (*)(void *, size_t, int, int, comm_t, hipStream_t))dlsym(v.lib, "ncclRecv");
+        }
         return v;
     }();
     return r;
@@ -186,13 +193,37 @@ int rccl_allgather_u32(void *comm, const unsigned int *send, unsigned int *recv,
     return rccl().AllGather(send, recv, count, kNcclUint32, comm, s);
 }
 
-// slot r of `base` (bytes first[r] .. first[r+1]) is broadcast from rank r, all slots in one group
-int rccl_allgatherv_bytes(void *comm, char *base, const size_t *first_byte, int n_ranks, hipStream_t s)
+// Which form the all-gather-v takes: 0 (default) one broadcast per slot, 1 point-to-point -- every rank sends its
+// slot to every peer and receives every peer's slot, all in one group: over a fully connected xGMI node a slot then
+// crosses each link once and no link carries another pair's data.  SIFTGPU_ALLGATHERV=p2p|bcast, read at every call
+// (the caller of a multi-rank run decides after trying both on the node at hand); every rank must use the same form.
+static int allgatherv_mode()
+{
+    const char *e = getenv("SIFTGPU_ALLGATHERV");
+    return e && strcmp(e, "p2p") == 0 ? 1 : 0;
+}
+
+// slot r of `base` (bytes first[r] .. first[r+1]) travels from rank r to every other rank
+int rccl_allgatherv_bytes(void *comm, char *base, const size_t *first_byte, int rank, int n_ranks, hipStream_t s)
 {
     const Rccl &r = rccl();
     int rc = r.GroupStart();
     if (rc != kNcclSuccess)
         return rc;
+    if (allgatherv_mode() == 1 && r.Send && r.Recv) {
+        const size_t mine = first_byte[rank + 1] - first_byte[rank];
+        for (int k = 0; k < n_ranks && rc == kNcclSuccess; k++) {
+            if (k == rank)
+                continue;
+            const size_t theirs = first_byte[k + 1] - first_byte[k];
+            if (mine) // (every rank sees the same counts: the peer posts the matching receive exactly when mine != 0)
+                rc = r.Send(base + first_byte[rank], mine, kNcclChar, k, comm, s);
+            if (theirs && rc == kNcclSuccess)
+                rc = r.Recv(base + first_byte[k], theirs, kNcclChar, k, comm, s);
+        }
+        const int rc_end = r.GroupEnd();
+        return rc != kNcclSuccess ? rc : rc_end;
+    }
     for (int k = 0; k < n_ranks; k++) {
         const size_t bytes = first_byte[k + 1] - first_byte[k];
         if (bytes == 0)

@@ -218,6 +218,6 @@ int rccl_comm_destroy(void *comm);
 int rccl_comm_shape(void *comm, int *rank, int *n_ranks);
 const char *rccl_error_string(int rc);
 int rccl_allgather_u32(void *comm, const unsigned int *send, unsigned int *recv, size_t count, hipStream_t s);
-int rccl_allgatherv_bytes(void *comm, char *base, const size_t *first_byte, int n_ranks, hipStream_t s);
+int rccl_allgatherv_bytes(void *comm, char *base, const size_t *first_byte, int rank, int n_ranks, hipStream_t s);
 
 } // namespace sg

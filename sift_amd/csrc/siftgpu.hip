@@ -1926,9 +1926,9 @@ int sg_allgather_features(sg_ctx *c, void *comm, const sg_packed_feature *d_feat
     launch_compact_feats(d_feats, d_counts, n_img, cap_per_image, d_all + rank_first[rank], s);
     HIPCHK(c, hipGetLastError());
     if (comm && n_ranks > 1) {
-        const int rc = rccl_allgatherv_bytes(comm, reinterpret_cast<char *>(d_all), first_byte.data(), n_ranks, s);
+        const int rc = rccl_allgatherv_bytes(comm, reinterpret_cast<char *>(d_all), first_byte.data(), rank, n_ranks, s);
         if (rc != 0) {
-            c->err = std::string("ncclBroadcast (all-gather-v): ") + rccl_error_string(rc);
+            c->err = std::string("all-gather-v (ncclBroadcast or ncclSend/ncclRecv group): ") + rccl_error_string(rc);
             return SG_E_HIP;
         }
     }

@@ -67,6 +67,7 @@ def test_bench_two_ranks_rehearsal_checks_the_exchange():
     assert line["n_gpus"] == 2 and "gloo" in line["exchange"]
     # the children met over their own rendezvous and failed where they must: at the communicator of two ranks on one GPU
     assert line["exchange_preflight"]["ok"] is False and "entering sg_comm_create" in line["exchange_preflight"]["this_rank"]
+    assert line["exchange_preflight"]["form"] is None and line["exchange_preflight"]["p2p"]["ok"] is False
     chk = line["exchange_check"]
     assert chk["ok"] is True and chk["ranks"] == 2 and chk["checksum_equal"] and chk["counts_equal"] and chk["own_slot_equal"]
     assert chk["features_gathered"] == line["features_gathered_last_step"] > 2 * 3 * 300
@@ -80,6 +81,8 @@ def test_exchange_preflight_child_world_of_one():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight-child"], capture_output=True,
                        text=True, timeout=300, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
+    forms = {d["form"]: d for d in (json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{"))}  # (RCCL prints too)
+    assert forms["bcast"]["ok"] is True and forms["p2p"]["ok"] is True and forms["bcast"]["ms"] > 0
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--preflight-child"], capture_output=True,
                        text=True, timeout=300, cwd=ROOT, env=dict(env, SIFT_BENCH_PREFLIGHT_FAIL="1"))
     assert r.returncode == 5

@@ -1032,9 +1032,12 @@ void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int 
     // bwork: per image [2][kRankBuckets]: counts (scanned in place to offsets), then scatter cursors
     const size_t bc_img = 2 * (size_t)kRankBuckets;
     (void)hipMemsetAsync(bwork, 0, sizeof(unsigned int) * bc_img * B, s);
+    // at most 256 workgroups per image in a batch; a frame alone (an 8K frame has 360 000 features, and equal scales by
+    // the thousand in one bucket) may take 4096, so that its in-bucket counting is spread over the chip
+    const unsigned int most = std::max(256u, 4096u / (unsigned int)(B > 0 ? B : 1));
     unsigned int blocks = (cap + 255) / 256;
-    if (blocks > 256)
-        blocks = 256;
+    if (blocks > most)
+        blocks = most;
     dim3 g(blocks, B);
     rank_hist_k<<<g, 256, 0, s>>>(fscale, fs_img_stride, feat_count, bwork, bc_img, cap);
     launch_scan(bwork, bc_img, kRankBuckets, scratch_totals, 0xffffffffu, overflow_dummy, B, s);

@@ -987,27 +987,32 @@ __global__ __launch_bounds__(256) void rank_hist_k(const double *fscale, size_t 
 
 __global__ __launch_bounds__(256) void rank_scatter_k(const double *fscale, size_t fs_img,
                                                       const unsigned int *feat_count, const unsigned int *boff,
-                                                      unsigned int *bcursor, size_t bc_img, unsigned int *blist,
+                                                      unsigned int *bcursor, size_t bc_img, RankEntry *blist,
                                                       size_t bl_img, unsigned int cap)
 {
     const int b = blockIdx.y;
     const unsigned int n = min(feat_count[b], cap);
     for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
-        unsigned int k = rank_bucket(fscale[(size_t)b * fs_img + i]);
+        const double sc = fscale[(size_t)b * fs_img + i];
+        unsigned int k = rank_bucket(sc);
         unsigned int pos = boff[(size_t)b * bc_img + k] + atomicAdd(&bcursor[(size_t)b * bc_img + k], 1u);
-        blist[(size_t)b * bl_img + pos] = i;
+        RankEntry e;
+        e.scale = sc;
+        e.index = i;
+        e.pad = 0;
+        blist[(size_t)b * bl_img + pos] = e;
     }
 }
 
 __global__ __launch_bounds__(256) void rank_count_k(const double *fscale, size_t fs_img, const unsigned int *feat_count,
                                                     const unsigned int *boff, size_t bc_img,
-                                                    const unsigned int *blist, size_t bl_img, unsigned int *rank,
+                                                    const RankEntry *blist, size_t bl_img, unsigned int *rank,
                                                     size_t rank_img, unsigned int cap)
 {
     const int b = blockIdx.y;
     const unsigned int n = min(feat_count[b], cap);
     const double *fsb = fscale + (size_t)b * fs_img;
-    const unsigned int *bl = blist + (size_t)b * bl_img;
+    const RankEntry *bl = blist + (size_t)b * bl_img;
     for (unsigned int i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
         const double my = fsb[i];
         const unsigned int k = rank_bucket(my);
@@ -1015,16 +1020,15 @@ __global__ __launch_bounds__(256) void rank_count_k(const double *fscale, size_t
         const unsigned int end = k + 1 < (unsigned int)kRankBuckets ? boff[(size_t)b * bc_img + k + 1] : n;
         unsigned int cnt = 0;
         for (unsigned int p = start; p < end; p++) {
-            const unsigned int j = bl[p];
-            const double s = fsb[j];
-            cnt += (s < my || (s == my && j < i)) ? 1u : 0u;
+            const RankEntry e = bl[p];
+            cnt += (e.scale < my || (e.scale == my && e.index < i)) ? 1u : 0u;
         }
         rank[(size_t)b * rank_img + i] = start + cnt;
     }
 }
 
 void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
-                 size_t rank_img_stride, unsigned int *bwork, unsigned int *blist, unsigned int *scratch_totals,
+                 size_t rank_img_stride, unsigned int *bwork, RankEntry *blist, unsigned int *scratch_totals,
                  unsigned int *overflow_dummy, unsigned int cap, int B, hipStream_t s)
 {
     if (cap == 0)

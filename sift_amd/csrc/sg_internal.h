@@ -183,9 +183,15 @@ void launch_feat_gather(const KpRec *kp, size_t kp_img_stride, const unsigned in
 void launch_descr(const OctaveTab &tab, const FeatRec *frec, size_t frec_img_stride, const unsigned int *feat_count,
                   uint8_t *desc, size_t desc_img_stride, double *prequant, size_t pq_img_stride, unsigned int cap,
                   int max_radius, int B, int prec, unsigned long long *trip_slots, hipStream_t s);
+// An entry of a scale bucket's list: the feature's index with its scale beside it, so that the counting inside a
+// bucket reads one contiguous stream instead of following every index to its scale.
+struct RankEntry {
+    double scale;
+    unsigned int index, pad;
+};
 // bwork: [B][2][kRankBuckets] scratch, blist: [B][cap] scratch, scratch_totals: [B], overflow_dummy: [1]
 void launch_rank(const double *fscale, size_t fs_img_stride, const unsigned int *feat_count, unsigned int *rank,
-                 size_t rank_img_stride, unsigned int *bwork, unsigned int *blist, unsigned int *scratch_totals,
+                 size_t rank_img_stride, unsigned int *bwork, RankEntry *blist, unsigned int *scratch_totals,
                  unsigned int *overflow_dummy, unsigned int cap, int B, hipStream_t s);
 // mode 0: packed features (sg_packed_feature) at out + b*out_img_stride*144; mode 1: sg_keypoint records;
 // mode 3: WireRec records (out 16-byte aligned).

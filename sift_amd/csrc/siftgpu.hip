@@ -157,7 +157,8 @@ struct sg_ctx {
     unsigned int *d_chunks = nullptr; // three arrays per image: detect, valid, peaks
     size_t chunks1 = 0, chunks2 = 0, chunks3 = 0, chunks_total = 0;
     unsigned int *d_cand = nullptr, *d_kpsrc = nullptr, *d_fsrc = nullptr, *d_rank = nullptr;
-    unsigned int *d_bwork = nullptr, *d_blist = nullptr, *d_rtot = nullptr; // rank scratch
+    unsigned int *d_bwork = nullptr, *d_rtot = nullptr; // rank scratch
+    RankEntry *d_blist = nullptr;
     KpRec *d_kp = nullptr;
     FeatRec *d_frec = nullptr;
     double *d_ori = nullptr, *d_pq = nullptr, *d_fscale = nullptr;
@@ -1059,7 +1060,7 @@ int sg_create(const sg_params *p_in, sg_ctx **out)
     ALLOC(c->d_overflow, sizeof(unsigned int) * 4);
     ALLOC(c->d_outcounts, sizeof(unsigned int) * B);
     ALLOC(c->d_bwork, sizeof(unsigned int) * 2 * kRankBuckets * B);
-    ALLOC(c->d_blist, sizeof(unsigned int) * (size_t)c->feat_cap * B);
+    ALLOC(c->d_blist, sizeof(RankEntry) * (size_t)c->feat_cap * B);
     ALLOC(c->d_rtot, sizeof(unsigned int) * (B + 1));
     for (int i = 0; i < kLevels; i++) {
         if (c->ntaps[i] <= kMaxTaps)
